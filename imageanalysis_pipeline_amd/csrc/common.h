@@ -1,0 +1,60 @@
+// Internal helpers shared by the HIP translation units of libiap_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/iap.h"
+
+namespace iap {
+
+void set_error(const char* fmt, ...);
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+#define IAP_REQUIRE(cond, code, ...)          \
+  do {                                        \
+    if (!(cond)) {                            \
+      iap::set_error(__VA_ARGS__);            \
+      return (code);                          \
+    }                                         \
+  } while (0)
+
+#define IAP_HIP(call)                                                                   \
+  do {                                                                                  \
+    hipError_t e__ = (call);                                                            \
+    if (e__ != hipSuccess) {                                                            \
+      iap::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__,  \
+                     __LINE__);                                                         \
+      return static_cast<int>(e__);                                                     \
+    }                                                                                   \
+  } while (0)
+
+#define IAP_LAUNCH_CHECK()                                                              \
+  do {                                                                                  \
+    hipError_t e__ = hipGetLastError();                                                 \
+    if (e__ != hipSuccess) {                                                            \
+      iap::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e__),        \
+                     __FILE__, __LINE__);                                               \
+      return static_cast<int>(e__);                                                     \
+    }                                                                                   \
+  } while (0)
+
+// 8 x u16 = one 16-byte lane access (guide G13: always vectorise 16-bit streams).
+struct alignas(16) u16x8 {
+  uint16_t v[8];
+};
+
+__device__ __forceinline__ u16x8 load8(const uint16_t* p) { return *reinterpret_cast<const u16x8*>(p); }
+__device__ __forceinline__ void store8(uint16_t* p, const u16x8& v) { *reinterpret_cast<u16x8*>(p) = v; }
+
+// XCD-aware block remap (guide T1): blocks b and b+8 share an XCD/L2; give each XCD a
+// contiguous range of logical tiles.  Bijective for any n.
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned n) {
+  unsigned q = n >> 3, r = n & 7u, x = b & 7u;
+  unsigned base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + (b >> 3);
+}
+
+}  // namespace iap

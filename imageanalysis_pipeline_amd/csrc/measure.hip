@@ -1,0 +1,310 @@
+// Per-label measurement: LDS-privatised segmented reduction keyed by label id.
+//
+// Replaces the O(labels x channels) full-frame compares of analysis.py:80-98 (mean
+// intensity), analysis.py:164-173 (centroid) and experiments.py:200-201 (area) by ONE pass
+// over the label plane and the C image planes.  All sums are exact integers (u32 partials
+// per workgroup chunk, u64 in HBM), so mean = (f64)sum/(f64)count reproduces numpy's
+// nanmean(where=) bit for bit.
+//
+// Kernel shape (HBM-bound, 2 + 2/C algorithmic bytes per stack pixel):
+//   grid = (chunks per frame, T); one 256-thread workgroup owns CHUNK consecutive pixels of
+//   the flattened (z,y,x) index space of one frame.  Each lane loads 8 labels (16 B) and
+//   8 pixels per channel, run-length-aggregates equal neighbouring labels in registers and
+//   adds the run to an open-addressing hash table in LDS (ds_add_u32); the table is flushed
+//   with one 64-bit global atomic per (label, field) per workgroup.  Label 0 (background,
+//   the bulk of the pixels) never touches the table: it is counted per lane and reduced
+//   with wave shuffles.
+#include "common.h"
+
+namespace iap {
+
+constexpr int MEAS_THREADS = 256;
+constexpr int MEAS_ITERS = 8;
+constexpr int MEAS_HASH_LOG2 = 9;
+constexpr int MEAS_HASH = 1 << MEAS_HASH_LOG2;  // slots per workgroup
+
+template <int NC>
+struct MeasTable {
+  unsigned key[MEAS_HASH];
+  unsigned cnt[MEAS_HASH];
+  unsigned sz[MEAS_HASH];
+  unsigned sy[MEAS_HASH];
+  unsigned sx[MEAS_HASH];
+  unsigned si[NC][MEAS_HASH];
+  unsigned bg;
+};
+
+template <int NC, bool COORDS>
+__device__ __forceinline__ void meas_flush_run(MeasTable<NC>& tb, unsigned lab, unsigned cnt, unsigned sz,
+                                               unsigned sy, unsigned sx, const unsigned (&si)[NC], int L,
+                                               unsigned long long* __restrict__ acc_frame, int F, int c0,
+                                               unsigned& bg) {
+  if (cnt == 0) return;
+  if (lab == 0) {
+    bg += cnt;
+    return;
+  }
+  if (lab >= (unsigned)L) return;
+  unsigned h = (lab * 2654435761u) >> (32 - MEAS_HASH_LOG2);
+  int probes = 0;
+  for (; probes < MEAS_HASH; ++probes) {
+    unsigned k = atomicCAS(&tb.key[h], 0u, lab);
+    if (k == 0u || k == lab) break;
+    h = (h + 1) & (MEAS_HASH - 1);
+  }
+  if (probes < MEAS_HASH) {
+    if (COORDS) {
+      atomicAdd(&tb.cnt[h], cnt);
+      atomicAdd(&tb.sz[h], sz);
+      atomicAdd(&tb.sy[h], sy);
+      atomicAdd(&tb.sx[h], sx);
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) atomicAdd(&tb.si[c][h], si[c]);
+  } else {  // table full (more than MEAS_HASH distinct labels in one chunk): straight to HBM
+    unsigned long long* a = acc_frame + (size_t)lab * F;
+    if (COORDS) {
+      atomicAdd(a + 0, (unsigned long long)cnt);
+      atomicAdd(a + 1, (unsigned long long)sz);
+      atomicAdd(a + 2, (unsigned long long)sy);
+      atomicAdd(a + 3, (unsigned long long)sx);
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) atomicAdd(a + 4 + c0 + c, (unsigned long long)si[c]);
+  }
+}
+
+// VEC = 8: 16-byte lane loads (needs ZYX % 8 == 0); VEC = 1: scalar fallback for odd sizes.
+template <int NC, bool COORDS, int VEC>
+__global__ __launch_bounds__(MEAS_THREADS) void measure_kernel(
+    const uint16_t* __restrict__ img, const uint16_t* __restrict__ labels, unsigned zyx, int C, int c0,
+    int Y, int X, int L, unsigned long long* __restrict__ acc) {
+  __shared__ MeasTable<NC> tb;
+  const int tid = threadIdx.x;
+  const unsigned t = blockIdx.y;
+  const int F = 4 + C;
+  for (int s = tid; s < MEAS_HASH; s += MEAS_THREADS) {
+    tb.key[s] = 0;
+    tb.cnt[s] = 0;
+    tb.sz[s] = 0;
+    tb.sy[s] = 0;
+    tb.sx[s] = 0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) tb.si[c][s] = 0;
+  }
+  if (tid == 0) tb.bg = 0;
+  __syncthreads();
+
+  const uint16_t* lab_f = labels + (size_t)t * zyx;
+  const uint16_t* img_f = img + ((size_t)t * C + c0) * zyx;
+  unsigned long long* acc_f = acc + (size_t)t * L * F;
+  const unsigned chunk = MEAS_THREADS * MEAS_ITERS * VEC;
+  const unsigned chunk0 = blockIdx.x * chunk;
+  const unsigned yx = (unsigned)Y * (unsigned)X;
+  unsigned bg = 0;
+
+#pragma unroll 2
+  for (int it = 0; it < MEAS_ITERS; ++it) {
+    unsigned p = chunk0 + (it * MEAS_THREADS + tid) * VEC;
+    if (p >= zyx) break;
+    uint16_t lv[VEC];
+    uint16_t iv[NC][VEC];
+    if (VEC == 8) {
+      u16x8 l8 = load8(lab_f + p);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) lv[i] = l8.v[i];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        u16x8 i8 = load8(img_f + (size_t)c * zyx + p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) iv[c][i] = i8.v[i];
+      }
+    } else {
+      lv[0] = lab_f[p];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) iv[c][0] = img_f[(size_t)c * zyx + p];
+    }
+    unsigned z = p / yx;
+    unsigned rem = p - z * yx;
+    unsigned y = rem / (unsigned)X;
+    unsigned x = rem - y * (unsigned)X;
+
+    unsigned cur = lv[0], cnt = 0, sz = 0, sy = 0, sx = 0;
+    unsigned si[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) si[c] = 0;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      unsigned lab = lv[i];
+      if (lab != cur) {
+        meas_flush_run<NC, COORDS>(tb, cur, cnt, sz, sy, sx, si, L, acc_f, F, c0, bg);
+        cur = lab;
+        cnt = sz = sy = sx = 0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) si[c] = 0;
+      }
+      cnt += 1;
+      sz += z;
+      sy += y;
+      sx += x;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) si[c] += iv[c][i];
+      if (++x == (unsigned)X) {  // a vector may straddle a row (X % 8 != 0) or a plane
+        x = 0;
+        if (++y == (unsigned)Y) {
+          y = 0;
+          ++z;
+        }
+      }
+    }
+    meas_flush_run<NC, COORDS>(tb, cur, cnt, sz, sy, sx, si, L, acc_f, F, c0, bg);
+  }
+
+  if (COORDS) {  // background count: wave shuffle reduction, one LDS add per wave
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bg += __shfl_down(bg, o, 64);
+    if ((tid & 63) == 0 && bg) atomicAdd(&tb.bg, bg);
+  }
+  __syncthreads();
+  for (int s = tid; s < MEAS_HASH; s += MEAS_THREADS) {
+    unsigned lab = tb.key[s];
+    if (lab) {
+      unsigned long long* a = acc_f + (size_t)lab * F;
+      if (COORDS) {
+        atomicAdd(a + 0, (unsigned long long)tb.cnt[s]);
+        if (tb.sz[s]) atomicAdd(a + 1, (unsigned long long)tb.sz[s]);
+        atomicAdd(a + 2, (unsigned long long)tb.sy[s]);
+        atomicAdd(a + 3, (unsigned long long)tb.sx[s]);
+      }
+#pragma unroll
+      for (int c = 0; c < NC; ++c) atomicAdd(a + 4 + c0 + c, (unsigned long long)tb.si[c][s]);
+    }
+  }
+  if (COORDS && tid == 0 && tb.bg && L > 0) atomicAdd(acc_f + 0, (unsigned long long)tb.bg);
+}
+
+__global__ __launch_bounds__(256) void measure_finalize_kernel(
+    const unsigned long long* __restrict__ acc, long long rows, int C, long long* __restrict__ area,
+    double* __restrict__ mean, double* __restrict__ cen, long long* __restrict__ cen_r) {
+  long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const int F = 4 + C;
+  const unsigned long long* a = acc + r * F;
+  unsigned long long n = a[0];
+  area[r] = (long long)n;
+  double dn = (double)n;
+  for (int c = 0; c < C; ++c) mean[r * C + c] = n ? (double)a[4 + c] / dn : 0.0;
+  for (int d = 0; d < 3; ++d) {
+    double m = n ? (double)a[1 + d] / dn : 0.0;
+    cen[r * 3 + d] = m;
+    cen_r[r * 3 + d] = (long long)rint(m);  // round-half-even == Python round(np.float64)
+  }
+}
+
+__global__ __launch_bounds__(256) void max_u16_kernel(const uint16_t* __restrict__ p, long long n,
+                                                      unsigned* __restrict__ out) {
+  unsigned m = 0;
+  long long nv = n >> 3;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+    u16x8 v = load8(p + i * 8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m = max(m, (unsigned)v.v[k]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) m = max(m, (unsigned)p[nv * 8 + threadIdx.x]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_down(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+template <int NC, bool COORDS>
+static int launch_measure(const uint16_t* img, const uint16_t* labels, int64_t T, int C, int c0, int Z,
+                          int Y, int X, int L, uint64_t* acc, hipStream_t st) {
+  unsigned zyx = (unsigned)((int64_t)Z * Y * X);
+  auto* a = reinterpret_cast<unsigned long long*>(acc);
+  if (zyx % 8 == 0) {
+    unsigned chunk = MEAS_THREADS * MEAS_ITERS * 8;
+    dim3 grid((zyx + chunk - 1) / chunk, (unsigned)T);
+    hipLaunchKernelGGL((measure_kernel<NC, COORDS, 8>), grid, dim3(MEAS_THREADS), 0, st, img, labels, zyx, C,
+                       c0, Y, X, L, a);
+  } else {
+    unsigned chunk = MEAS_THREADS * MEAS_ITERS;
+    dim3 grid((zyx + chunk - 1) / chunk, (unsigned)T);
+    hipLaunchKernelGGL((measure_kernel<NC, COORDS, 1>), grid, dim3(MEAS_THREADS), 0, st, img, labels, zyx, C,
+                       c0, Y, X, L, a);
+  }
+  IAP_LAUNCH_CHECK();
+  return IAP_OK;
+}
+
+}  // namespace iap
+
+using namespace iap;
+
+extern "C" int iap_measure_labels_u16(const uint16_t* img, const uint16_t* labels, int64_t T, int C, int Z,
+                                      int Y, int X, int L, uint64_t* acc, void* stream) {
+  IAP_REQUIRE(img && labels && acc, IAP_E_ARG, "iap_measure_labels_u16: null pointer");
+  IAP_REQUIRE(T > 0 && C > 0 && Z > 0 && Y > 0 && X > 0 && L > 0, IAP_E_ARG,
+              "iap_measure_labels_u16: non-positive size (T=%lld C=%d Z=%d Y=%d X=%d L=%d)", (long long)T, C,
+              Z, Y, X, L);
+  IAP_REQUIRE(L <= 65536, IAP_E_ARG, "iap_measure_labels_u16: L=%d exceeds the u16 label range", L);
+  IAP_REQUIRE((int64_t)Z * Y * X < (1ll << 31), IAP_E_UNSUPPORTED,
+              "iap_measure_labels_u16: Z*Y*X must be below 2^31");
+  IAP_REQUIRE(T <= 65535, IAP_E_UNSUPPORTED, "iap_measure_labels_u16: T must be <= 65535 per call");
+  IAP_REQUIRE(Y <= 65536, IAP_E_UNSUPPORTED, "iap_measure_labels_u16: Y must be <= 65536");
+  IAP_REQUIRE(aligned16(img) && aligned16(labels) && (reinterpret_cast<uintptr_t>(acc) & 7u) == 0, IAP_E_ALIGN,
+              "iap_measure_labels_u16: img/labels must be 16-byte and acc 8-byte aligned");
+  hipStream_t st = as_stream(stream);
+  IAP_HIP(hipMemsetAsync(acc, 0, (size_t)T * L * (4 + C) * sizeof(uint64_t), st));
+  // channel groups of <= 4 keep every accumulator in registers; the first group also
+  // carries count and coordinate sums.
+  for (int c0 = 0; c0 < C; c0 += 4) {
+    int nc = C - c0 < 4 ? C - c0 : 4;
+    int rc;
+    bool first = c0 == 0;
+#define IAP_MEAS_CASE(N)                                                                                  \
+  case N:                                                                                                 \
+    rc = first ? launch_measure<N, true>(img, labels, T, C, c0, Z, Y, X, L, acc, st)                      \
+               : launch_measure<N, false>(img, labels, T, C, c0, Z, Y, X, L, acc, st);                    \
+    break;
+    switch (nc) {
+      IAP_MEAS_CASE(1)
+      IAP_MEAS_CASE(2)
+      IAP_MEAS_CASE(3)
+      IAP_MEAS_CASE(4)
+      default:
+        rc = IAP_E_ARG;
+    }
+#undef IAP_MEAS_CASE
+    if (rc) return rc;
+  }
+  return IAP_OK;
+}
+
+extern "C" int iap_measure_finalize(const uint64_t* acc, int64_t T, int L, int C, int64_t* area, double* mean,
+                                    double* centroid, int64_t* centroid_rne, void* stream) {
+  IAP_REQUIRE(acc && area && mean && centroid && centroid_rne, IAP_E_ARG, "iap_measure_finalize: null pointer");
+  IAP_REQUIRE(T > 0 && L > 0 && C > 0, IAP_E_ARG, "iap_measure_finalize: non-positive size");
+  long long rows = (long long)T * L;
+  unsigned blocks = (unsigned)((rows + 255) / 256);
+  hipLaunchKernelGGL(measure_finalize_kernel, dim3(blocks), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const unsigned long long*>(acc), rows, C,
+                     reinterpret_cast<long long*>(area), mean, centroid, reinterpret_cast<long long*>(centroid_rne));
+  IAP_LAUNCH_CHECK();
+  return IAP_OK;
+}
+
+extern "C" int iap_max_u16(const uint16_t* labels, int64_t n, uint32_t* out, void* stream) {
+  IAP_REQUIRE(labels && out, IAP_E_ARG, "iap_max_u16: null pointer");
+  IAP_REQUIRE(n > 0, IAP_E_ARG, "iap_max_u16: n must be positive");
+  IAP_REQUIRE(aligned16(labels), IAP_E_ALIGN, "iap_max_u16: labels must be 16-byte aligned");
+  hipStream_t st = as_stream(stream);
+  IAP_HIP(hipMemsetAsync(out, 0, sizeof(uint32_t), st));
+  long long nv = n >> 3;
+  unsigned blocks = (unsigned)((nv + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks == 0) blocks = 1;
+  hipLaunchKernelGGL(max_u16_kernel, dim3(blocks), dim3(256), 0, st, labels, (long long)n, out);
+  IAP_LAUNCH_CHECK();
+  return IAP_OK;
+}

@@ -1,0 +1,138 @@
+/*
+ * iap.h -- C-ABI of libiap_hip.so: the MI355X (gfx950) hot path behind the reference's
+ * background-subtract -> register -> per-label-measure stages.
+ *
+ * Every entry point takes raw DEVICE pointers, sizes and a hipStream_t passed as void*;
+ * the caller owns every buffer (in the Python host: torch tensors); the library never
+ * allocates: scratch comes from the `ws` argument (query the size with the matching
+ * *_ws_bytes function).  All work is enqueued on `stream`; nothing synchronises with the
+ * host.  Return value: 0 = ok, negative = invalid argument (IAP_E_*), positive = the
+ * hipError_t of a failed runtime call.  iap_last_error() returns a thread-local message.
+ *
+ * Stack layout (reference utility.py:487-524 load_stack, planar on disk):
+ *   images  u16 [T][C][Z][Y][X]   contiguous, X fastest
+ *   labels  u16 [T][Z][Y][X]      (utility.py:616-618 save_mask writes uint16)
+ *
+ * Each declaration cites the reference code it replaces (paths under pipeline/).
+ */
+#ifndef IAP_H
+#define IAP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IAP_OK 0
+#define IAP_E_ARG (-1)       /* null pointer / non-positive size / bad enum          */
+#define IAP_E_ALIGN (-2)     /* pointer not 16-byte aligned                          */
+#define IAP_E_WS (-3)        /* workspace too small                                  */
+#define IAP_E_UNSUPPORTED (-4) /* size outside what the kernels are built for       */
+
+/* library / build identification; iap_last_error: message of the last failing call on this thread */
+const char* iap_version(void);
+const char* iap_last_error(void);
+
+/* ------------------------------------------------------------------ background ------- */
+
+/* SMO operator value per pixel (float32) of n planes.  in_kind: 0 = u16 planes, 1 = f32 planes.
+ * Replaces smo.SMO.smo_image as used by utility.py:252,260 (null-distribution threshold and
+ * tests).  sigma > 0 adds the gaussian pre-smoothing (scipy 'reflect', truncate 4). */
+int iap_smo_image(const void* in, int in_kind, float* out, int64_t n, int Y, int X,
+                  float sigma, int size, void* stream);
+
+/* Workspace bytes for iap_bg_smo_u16 on n planes. */
+size_t iap_bg_smo_ws_bytes(int64_t n, int Y, int X);
+
+/* utility.py:255-264 smo_bg_sub hot loop, for n independent u16 planes:
+ *   mask = SMO(plane) < threshold ; med = median(plane[mask]) ;
+ *   out = trunc(max(plane - med, 0)) as u16.           in == out is allowed (in place).
+ * med2_out (optional, device int32[n]) receives 2*median (half-integers are possible);
+ * nbg_out (optional, device int32[n]) the number of background pixels. */
+int iap_bg_smo_u16(const uint16_t* in, uint16_t* out, int64_t n, int Y, int X,
+                   float sigma, int size, float threshold,
+                   int32_t* med2_out, int32_t* nbg_out,
+                   void* ws, size_t ws_bytes, void* stream);
+
+/* utility.py:228-233 man_bg_sub arithmetic for n planes: bg = rint(mean(ROI)) per plane
+ * (ROI rows r0..r1, cols c0..c1 inclusive, identical for all planes), out = max(in-bg,0).
+ * bg_out (optional, device int32[n]).  ws: n * 16 bytes. */
+int iap_bg_const_u16(const uint16_t* in, uint16_t* out, int64_t n, int Y, int X,
+                     int r0, int c0, int r1, int c1, int32_t* bg_out,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* utility.py:462 blur_img: cv2.GaussianBlur(im,(kx,ky),sigma).astype(uint16) semantics,
+ * reflect-101 border, fp32 taps, round-half-even + saturate.  kx, ky odd, <= 63. */
+int iap_gauss_blur_u16(const uint16_t* in, uint16_t* out, int64_t n, int Y, int X,
+                       int kx, int ky, float sigma, void* stream);
+
+/* ------------------------------------------------------------------ registration ----- */
+
+#define IAP_REF_FIRST 0     /* utility.py:332-355 */
+#define IAP_REF_MEAN 1      /* utility.py:356-380 */
+#define IAP_REF_PREVIOUS 2  /* utility.py:381-413 */
+
+#define IAP_REG_UPSAMPLE 1   /* sub-pixel refinement (0.1 px matrix-DFT grid + parabola)   */
+#define IAP_REG_NORMALIZE 2  /* phase-normalise the cross-power spectrum (default: plain)  */
+
+/* np.amax(stack, axis=z) of utility.py:335,341: in u16 [n][Z][Y][X] -> out u16 [n][Y][X];
+ * in_stride = elements between consecutive items of `in`. */
+int iap_mip_u16(const uint16_t* in, int64_t in_stride, uint16_t* out, int64_t n, int Z, int Y, int X,
+                void* stream);
+
+/* Workspace bytes for iap_reg_estimate_u16 / iap_im_reg_u16 processing `batch` frames per
+ * launch group (batch >= 1).  Y, X are plane sizes; the FFT window is the centred
+ * power-of-two crop (<= 4096) of each axis. */
+size_t iap_reg_ws_bytes(int Y, int X, int Z, int batch);
+
+/* Translation estimate (replaces pystackreg StackReg.register, utility.py:340,365,393) for n
+ * moving planes against one reference plane (ref_kind 0: u16, 1: u32 sum-of-planes, 2: f32).
+ * mov planes are `mov_stride` elements apart.  shifts_out: device f64 [n][2] = (dy, dx) to
+ * APPLY to each moving plane (scipy.ndimage.shift convention). */
+int iap_reg_estimate_u16(const void* ref, int ref_kind, const uint16_t* mov, int64_t mov_stride,
+                         int64_t n, int Y, int X, int flags, double* shifts_out,
+                         void* ws, size_t ws_bytes, void* stream);
+
+/* StackReg.transform + clip + astype(uint16) of utility.py:351-355 fused over a stack:
+ * n_frames frames of planes_per_frame planes each; frame f is warped by shifts[f] (device f64
+ * [n][2]): out[y][x] = cubic-spline(in)(y-dy, x-dx), outside -> 0, negatives -> 0, truncate,
+ * saturate at 65535.  Integer shifts are exact copies.  in != out. */
+int iap_apply_shift_u16(const uint16_t* in, uint16_t* out, int64_t n_frames, int64_t planes_per_frame,
+                        int Y, int X, const double* shifts, void* stream);
+
+/* utility.py:274-430 im_reg (translation) on a resident stack u16 [T][C][Z][Y][X]:
+ * estimate on channel reg_channel (z-MIP), reference per ref_mode, apply to every channel and
+ * plane.  out: same shape (must not alias in).  shifts_out: device f64 [T][2]. */
+int iap_im_reg_u16(const uint16_t* in, uint16_t* out, int64_t T, int C, int Z, int Y, int X,
+                   int reg_channel, int ref_mode, int flags, double* shifts_out,
+                   void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------ measurement ------ */
+
+/* Number of u64 accumulator fields per (frame, label): count, sum_z, sum_y, sum_x, sum_I[C]. */
+#define IAP_ACC_FIELDS(C) (4 + (C))
+
+/* analysis.py:80-98 (mean intensity), :164-173 (centroid), experiments.py:200-201 (area):
+ * one pass over image + label stack accumulating exact integer sums per (frame, label):
+ *   acc u64 [T][L][4+C], zeroed by this call; labels >= L are ignored (pass L = max+1).
+ * Label 0 only gets its count (it is the value np.unique(...)[1:] normally drops). */
+int iap_measure_labels_u16(const uint16_t* img, const uint16_t* labels,
+                           int64_t T, int C, int Z, int Y, int X, int L,
+                           uint64_t* acc, void* stream);
+
+/* Accumulators -> tables (device): area i64 [T][L]; mean f64 [T][L][C] = (f64)sum/(f64)count
+ * (numpy nanmean(where=) semantics, bit-exact); centroid f64 [T][L][3] (z,y,x);
+ * centroid_rne i64 [T][L][3] (round-half-even, Python round()).  Rows with count 0: all 0. */
+int iap_measure_finalize(const uint64_t* acc, int64_t T, int L, int C,
+                         int64_t* area, double* mean, double* centroid, int64_t* centroid_rne,
+                         void* stream);
+
+/* Max label value of a u16 label stack of n elements -> device u32 (zeroed by the call). */
+int iap_max_u16(const uint16_t* labels, int64_t n, uint32_t* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IAP_H */

@@ -1,0 +1,480 @@
+"""CPU ORACLE (test infrastructure, NOT product code).
+
+numpy-only restatement of the reference's background-subtract -> register ->
+per-label-measure path.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import this module; the shipped
+package (``imageanalysis_pipeline_amd``) never does.
+
+Pinning status
+-------------------------------------
+* ``measure_labels*``  : follows ``pipeline/analysis.py:80,98,164-173`` and numpy's
+  ``mean(where=)`` semantics exactly; cross-checked against
+  ``skimage.measure.regionprops`` (tests/golden/make_golden.py).  PINNED.
+* ``bg_manual``        : ``pipeline/utility.py:228-233``; fully determined by numpy.  PINNED
+  (by construction: it *is* the reference arithmetic).
+* ``bg_smo``           : ``pipeline/utility.py:252-264`` + the published SMO operator
+  (Silberberg & Grecco).  The ``smo`` package is an un-vendored, unpinned dependency
+  that is absent from this image -> PARITY UNPINNED.  Filters are cross-checked
+  against ``scipy.ndimage`` only.
+* ``gauss_blur``       : ``pipeline/utility.py:462`` (``cv2.GaussianBlur``; cv2 absent)
+  -> PARITY UNPINNED (build-defined: fp32 taps, reflect-101, RNE, saturate).
+* ``phase_shift`` / ``apply_shift`` : the reference calls ``pystackreg`` (absent,
+  unpinned; ``pipeline/utility.py:306,340,351``).  north_star replaces TurboReg by FFT
+  phase correlation -> PARITY UNPINNED versus pystackreg; the estimator is
+  cross-checked against ``skimage.registration.phase_cross_correlation`` and the
+  warp against ``scipy.ndimage.shift(order=3, mode='constant')``.
+
+Conventions
+-----------
+``shift = phase_shift(ref, mov)`` is the (dy, dx) to *apply* to ``mov`` so that it
+overlays ``ref`` -- the skimage convention -- and ``apply_shift(img, dy, dx)``
+computes ``out[y, x] = img[y - dy, x - dx]`` (``scipy.ndimage.shift`` convention).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# helpers shared by several stages
+# --------------------------------------------------------------------------------------
+
+
+def to_u16_trunc(a: np.ndarray) -> np.ndarray:
+    """``a[a<0]=0; a.astype(np.uint16)`` as in utility.py:262-264 / 354-355, except that
+    values above 65535 saturate (the reference wraps there: undefined-looking behaviour
+    the build deliberately replaces; SURVEY.md section 7 'hard parts')."""
+    a = np.where(a < 0, 0, a)
+    a = np.minimum(a, 65535)
+    return np.trunc(a).astype(np.uint16)
+
+
+def _reflect_index(i: np.ndarray, n: int) -> np.ndarray:
+    """scipy 'reflect' (half-sample symmetric): d c b a | a b c d | d c b a."""
+    p = 2 * n
+    i = np.mod(i, p)
+    return np.where(i >= n, p - 1 - i, i)
+
+
+def _reflect101_index(i: np.ndarray, n: int) -> np.ndarray:
+    """OpenCV BORDER_REFLECT_101 / scipy 'mirror': d c b | a b c d | c b a."""
+    if n == 1:
+        return np.zeros_like(i)
+    p = 2 * (n - 1)
+    i = np.mod(i, p)
+    return np.where(i >= n, p - i, i)
+
+
+# --------------------------------------------------------------------------------------
+# a1: SMO background subtraction  (utility.py:242-270)
+# --------------------------------------------------------------------------------------
+
+
+def _gauss_taps_scipy(sigma: float, truncate: float = 4.0) -> np.ndarray:
+    r = int(truncate * float(sigma) + 0.5)
+    x = np.arange(-r, r + 1, dtype=np.float64)
+    w = np.exp(-0.5 * x * x / (sigma * sigma))
+    return w / w.sum()
+
+
+def _corr1d_reflect(a: np.ndarray, w: np.ndarray, axis: int) -> np.ndarray:
+    r = (len(w) - 1) // 2
+    n = a.shape[axis]
+    out = np.zeros(a.shape, dtype=np.float64)
+    idx = np.arange(n)
+    for k in range(-r, r + 1):
+        out += w[k + r] * np.take(a, _reflect_index(idx + k, n), axis=axis)
+    return out
+
+
+def smo_image(img: np.ndarray, sigma: float = 0.0, size: int = 7) -> np.ndarray:
+    """SMO (Silver Mountain Operator) value per pixel, float64.
+
+    image.astype(float) -> [gaussian(sigma)] -> np.gradient -> unit gradient vectors
+    (zero gradient -> zero vector) -> uniform_filter(size) per component -> norm.
+    Boundary: scipy.ndimage default 'reflect' for both filters.
+    """
+    a = np.asarray(img).astype(np.float64)
+    if sigma and sigma > 0:
+        w = _gauss_taps_scipy(sigma)
+        a = _corr1d_reflect(_corr1d_reflect(a, w, 0), w, 1)
+    gy, gx = np.gradient(a)
+    nrm = np.sqrt(gy * gy + gx * gx)
+    ok = nrm > 0
+    ny = np.zeros_like(a)
+    nx = np.zeros_like(a)
+    np.divide(gy, nrm, out=ny, where=ok)
+    np.divide(gx, nrm, out=nx, where=ok)
+    box = np.full(size, 1.0 / size)
+    my = _corr1d_reflect(_corr1d_reflect(ny, box, 0), box, 1)
+    mx = _corr1d_reflect(_corr1d_reflect(nx, box, 0), box, 1)
+    return np.sqrt(my * my + mx * mx)
+
+
+def smo_threshold(shape, sigma: float = 0.0, size: int = 7, seed: int = 0, q: float = 0.05) -> float:
+    """5 % quantile of the SMO value of a normal-noise image of the given shape.
+    The reference draws this image unseeded (utility.py:252); the build seeds it and
+    passes the threshold explicitly."""
+    rng = np.random.default_rng(seed)
+    null = rng.standard_normal(size=shape)
+    return float(np.quantile(smo_image(null, sigma, size), q))
+
+
+def bg_smo(img: np.ndarray, threshold: float, sigma: float = 0.0, size: int = 7):
+    """Returns (out_u16, median_times_2, n_bg, mask).  median_times_2 is an integer:
+    np.median of an even count can be a half-integer."""
+    s = smo_image(img, sigma, size)
+    mask = s < threshold
+    sel = np.asarray(img)[mask]
+    if sel.size == 0:
+        med = 0.0
+    else:
+        med = float(np.median(sel))
+    out = to_u16_trunc(np.asarray(img).astype(np.float64) - med)
+    return out, int(round(2 * med)), int(sel.size), mask
+
+
+# --------------------------------------------------------------------------------------
+# a2: manual background subtraction  (utility.py:213-233)
+# --------------------------------------------------------------------------------------
+
+
+def bg_manual(img: np.ndarray, r0: int, c0: int, r1: int, c1: int) -> tuple[np.ndarray, int]:
+    """ROI = rows r0..r1, cols c0..c1 inclusive (skimage.draw.rectangle semantics);
+    bg = int(rint(mean(float32 ROI))) ; subtract ; clip ; u16."""
+    im = np.asarray(img).astype(np.float32)
+    roi = im[r0:r1 + 1, c0:c1 + 1]
+    # Reference: np.mean over a fancy-indexed float32 array (float32 pairwise sum).  The
+    # exact integer mean is used here; they differ only when the float32 pairwise sum
+    # rounds across a .5 tie (documented tolerance).
+    s = int(np.asarray(img)[r0:r1 + 1, c0:c1 + 1].astype(np.int64).sum())
+    n = roi.size
+    bg = int(np.rint(s / n))
+    out = im.astype(np.float64) - bg
+    return to_u16_trunc(out), bg
+
+
+# --------------------------------------------------------------------------------------
+# a3: Gaussian blur  (utility.py:462, cv2.GaussianBlur semantics, build-defined)
+# --------------------------------------------------------------------------------------
+
+
+def gauss_taps_cv(ksize: int, sigma: float) -> np.ndarray:
+    """cv2.getGaussianKernel(ksize, sigma, CV_32F): sigma<=0 -> 0.3*((k-1)*0.5-1)+0.8."""
+    if sigma <= 0:
+        sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8
+    x = np.arange(ksize, dtype=np.float64) - (ksize - 1) * 0.5
+    w = np.exp(-(x * x) / (2.0 * sigma * sigma))
+    return (w / w.sum()).astype(np.float32)
+
+
+def _sym_fir_f32(a: np.ndarray, w: np.ndarray, axis: int) -> np.ndarray:
+    """fp32 symmetric FIR, reflect-101, summation order
+    s = w0*x0; s += wi*(x[-i] + x[+i]) for i = 1..r  (unfused mul/add)."""
+    r = (len(w) - 1) // 2
+    n = a.shape[axis]
+    idx = np.arange(n)
+    s = (w[r] * np.take(a, idx, axis=axis)).astype(np.float32)
+    for i in range(1, r + 1):
+        lo = np.take(a, _reflect101_index(idx - i, n), axis=axis)
+        hi = np.take(a, _reflect101_index(idx + i, n), axis=axis)
+        s = (s + (w[r + i] * (lo + hi).astype(np.float32)).astype(np.float32)).astype(np.float32)
+    return s
+
+
+def gauss_blur(img: np.ndarray, ksize=(15, 15), sigma: float = 5.0) -> np.ndarray:
+    """ksize = (kx, ky) as in cv2; row (x) pass first, then column (y) pass; RNE + saturate."""
+    kx, ky = ksize
+    a = np.asarray(img).astype(np.float32)
+    a = _sym_fir_f32(a, gauss_taps_cv(kx, sigma), axis=1)
+    a = _sym_fir_f32(a, gauss_taps_cv(ky, sigma), axis=0)
+    return np.clip(np.rint(a), 0, 65535).astype(np.uint16)
+
+
+# --------------------------------------------------------------------------------------
+# a4: translation estimate by FFT phase correlation
+# --------------------------------------------------------------------------------------
+
+COARSE_HALF = 7      # stage 1: offsets -0.7 .. +0.7 in steps of 0.1
+FINE_HALF = 10       # stage 2: offsets -0.10 .. +0.10 in steps of 0.01
+
+
+def fft_window(n: int) -> int:
+    """Largest power of two <= n, capped at 4096 (the estimate uses the centred crop)."""
+    p = 1 << (int(n).bit_length() - 1)
+    return min(p, 4096)
+
+
+def _crop_center(a: np.ndarray) -> np.ndarray:
+    y, x = a.shape
+    py, px = fft_window(y), fft_window(x)
+    oy, ox = (y - py) // 2, (x - px) // 2
+    return a[oy:oy + py, ox:ox + px]
+
+
+def cross_power(ref: np.ndarray, mov: np.ndarray) -> np.ndarray:
+    """Normalised cross-power spectrum R = F conj(G) / |F conj(G)| (0 where |.| == 0)."""
+    f = np.fft.fft2(_crop_center(np.asarray(ref, dtype=np.float64)))
+    g = np.fft.fft2(_crop_center(np.asarray(mov, dtype=np.float64)))
+    p = f * np.conj(g)
+    m = np.abs(p)
+    r = np.zeros_like(p)
+    np.divide(p, m, out=r, where=m > 0)
+    return r
+
+
+def _upsampled(r: np.ndarray, ys: np.ndarray, xs: np.ndarray) -> np.ndarray:
+    """Real part of sum_uv R[u,v] exp(2 pi i (u y/Ny + v x/Nx)) for fractional y, x."""
+    ny, nx = r.shape
+    fu = np.fft.fftfreq(ny) * ny  # signed integer frequencies
+    fv = np.fft.fftfreq(nx) * nx
+    ky = np.exp(2j * np.pi * np.outer(ys, fu) / ny)   # (len(ys), ny)
+    kx = np.exp(2j * np.pi * np.outer(fv, xs) / nx)   # (nx, len(xs))
+    return (ky @ r @ kx).real / (ny * nx)
+
+
+def _parabola(vm: float, v0: float, vp: float) -> float:
+    den = vm - 2.0 * v0 + vp
+    if den >= 0:
+        return 0.0
+    d = 0.5 * (vm - vp) / den
+    return float(min(0.5, max(-0.5, d)))
+
+
+def phase_shift(ref: np.ndarray, mov: np.ndarray, upsample: bool = True) -> tuple[float, float]:
+    """(dy, dx) to apply to ``mov`` to register it onto ``ref``.
+
+    coarse : argmax (first in row-major order) of the real inverse FFT of R, wrapped to
+             the signed range (index > N/2 -> index - N), as skimage
+             _phase_cross_correlation.py:204-220.
+    fine   : two-stage matrix-DFT upsampling (0.1 px grid over +-0.7, then 0.01 px grid
+             over +-0.10; the Guizar-Sicairos scheme of skimage :232-250, made
+             hierarchical), finished by a 1-D parabolic vertex per axis on the 0.01 grid.
+    """
+    r = cross_power(ref, mov)
+    ny, nx = r.shape
+    c = np.fft.ifft2(r).real
+    k = int(np.argmax(c))
+    py, px = divmod(k, nx)
+    sy = py - ny if py > ny // 2 else py
+    sx = px - nx if px > nx // 2 else px
+    if not upsample:
+        return float(sy), float(sx)
+    cy, cx = float(sy), float(sx)
+    for half, step in ((COARSE_HALF, 0.1), (FINE_HALF, 0.01)):
+        offs = np.arange(-half, half + 1) * step
+        v = _upsampled(r, cy + offs, cx + offs)
+        k = int(np.argmax(v))
+        iy, ix = divmod(k, len(offs))
+        last = (iy, ix, v, offs, step)
+        cy, cx = cy + offs[iy], cx + offs[ix]
+    iy, ix, v, offs, step = last
+    n = len(offs)
+    if 0 < iy < n - 1:
+        cy += step * _parabola(v[iy - 1, ix], v[iy, ix], v[iy + 1, ix])
+    if 0 < ix < n - 1:
+        cx += step * _parabola(v[iy, ix - 1], v[iy, ix], v[iy, ix + 1])
+    return float(cy), float(cx)
+
+
+# --------------------------------------------------------------------------------------
+# a5: apply shift (cubic B-spline, mirror prefilter, zero outside), utility.py:351-355
+# --------------------------------------------------------------------------------------
+
+_Z1 = math.sqrt(3.0) - 2.0
+
+
+def _bspline3(t: float) -> float:
+    t = abs(t)
+    if t < 1:
+        return 2.0 / 3.0 - t * t + 0.5 * t * t * t
+    if t < 2:
+        return (2.0 - t) ** 3 / 6.0
+    return 0.0
+
+
+def cardinal_taps(frac: float, radius: int = 24) -> np.ndarray:
+    """taps h[k], k=-radius..radius+1, such that out(i0+frac) = sum_k h[k] s(i0+k):
+    cubic B-spline evaluation convolved with the (infinite, here truncated) inverse
+    B-spline filter g[m] = (-6 z1 / (1 - z1^2)) z1^|m|."""
+    c0 = -6.0 * _Z1 / (1.0 - _Z1 * _Z1)
+    ks = np.arange(-radius, radius + 2)
+    h = np.zeros(len(ks), dtype=np.float64)
+    for j in (-1, 0, 1, 2):
+        w = _bspline3(frac - j)
+        h += w * c0 * _Z1 ** np.abs(ks - j)
+    return h
+
+
+def _shift_axis(a: np.ndarray, d: float, axis: int) -> np.ndarray:
+    n = a.shape[axis]
+    i = np.arange(n)
+    x = i - d                       # source coordinate of each output sample
+    i0 = np.floor(x).astype(np.int64)
+    frac = float(-d - math.floor(-d))  # identical for every sample of a pure translation
+    inside = (x >= 0) & (x <= n - 1)
+    radius = 24
+    h = cardinal_taps(frac, radius)
+    out = np.zeros(a.shape, dtype=np.float64)
+    for t, k in enumerate(range(-radius, radius + 2)):
+        src = _reflect101_index(i0 + k, n)
+        out += h[t] * np.take(a, src, axis=axis)
+    shape = [1] * a.ndim
+    shape[axis] = n
+    return out * inside.reshape(shape)
+
+
+def apply_shift_f64(img: np.ndarray, dy: float, dx: float) -> np.ndarray:
+    """float64 result of the cubic-spline shift (== scipy.ndimage.shift(order=3,
+    mode='constant', cval=0) up to the 0.268^25 tap truncation)."""
+    a = np.asarray(img).astype(np.float64)
+    if float(dy) != 0.0:
+        a = _shift_axis(a, float(dy), 0) if float(dy) != round(dy) else _shift_int_axis(a, int(round(dy)), 0)
+    if float(dx) != 0.0:
+        a = _shift_axis(a, float(dx), 1) if float(dx) != round(dx) else _shift_int_axis(a, int(round(dx)), 1)
+    return a
+
+
+def _shift_int_axis(a: np.ndarray, d: int, axis: int) -> np.ndarray:
+    out = np.zeros_like(a)
+    n = a.shape[axis]
+    if abs(d) >= n:
+        return out
+    src = [slice(None)] * a.ndim
+    dst = [slice(None)] * a.ndim
+    if d >= 0:
+        src[axis] = slice(0, n - d)
+        dst[axis] = slice(d, n)
+    else:
+        src[axis] = slice(-d, n)
+        dst[axis] = slice(0, n + d)
+    out[tuple(dst)] = a[tuple(src)]
+    return out
+
+
+def apply_shift(img: np.ndarray, dy: float, dx: float) -> np.ndarray:
+    """u16 plane -> u16 plane: warp, clip negatives, truncate (utility.py:354-355).
+    Integer shifts are exact copies with zero fill."""
+    return to_u16_trunc(apply_shift_f64(img, dy, dx))
+
+
+# --------------------------------------------------------------------------------------
+# im_reg stack logic (utility.py:332-413)
+# --------------------------------------------------------------------------------------
+
+
+def mip(vol: np.ndarray) -> np.ndarray:
+    """np.amax over z (utility.py:335,341)."""
+    return np.amax(vol, axis=0)
+
+
+def im_reg_stack(stack: np.ndarray, reg_channel: int = 0, reg_ref: str = "mean", upsample: bool = True):
+    """stack: u16 (T, C, Z, Y, X).  Returns (registered u16 stack, shifts (T, 2) f64).
+
+    'first'   : ref = frame 0 (MIP over z)                       utility.py:332-355
+    'mean'    : ref = float64 mean over T of the MIPs            utility.py:356-380
+    'previous': ref = previous *registered, quantised* frame;    utility.py:381-413
+                frame 0 is copied verbatim.
+    One (dy, dx) per frame, applied to every channel and z-plane.
+    """
+    if reg_ref not in ("first", "previous", "mean"):
+        raise ValueError(f"{reg_ref} is not valid. Please only put ['first', 'previous', 'mean']")
+    t, c, z, y, x = stack.shape
+    out = np.zeros_like(stack)
+    shifts = np.zeros((t, 2), dtype=np.float64)
+    mips = lambda s, f: mip(s[f, reg_channel])  # noqa: E731
+    if reg_ref == "first":
+        ref = mips(stack, 0).astype(np.float64)
+    elif reg_ref == "mean":
+        ref = np.mean(np.stack([mips(stack, f) for f in range(t)]), axis=0)
+    for f in range(t):
+        if reg_ref == "previous":
+            if f == 0:
+                out[0] = stack[0]
+                continue
+            ref = mips(out, f - 1).astype(np.float64)
+        dy, dx = phase_shift(ref, mips(stack, f), upsample=upsample)
+        shifts[f] = (dy, dx)
+        for ch in range(c):
+            for zz in range(z):
+                out[f, ch, zz] = apply_shift(stack[f, ch, zz], dy, dx)
+    return out, shifts
+
+
+# --------------------------------------------------------------------------------------
+# a7/a8/a9: per-label measurement  (analysis.py:80,98,164-173; experiments.py:200-201)
+# --------------------------------------------------------------------------------------
+
+
+def measure_labels_literal(img: np.ndarray, labels: np.ndarray):
+    """The reference's own loop.  img: (C, [Z,] Y, X) u16; labels: ([Z,] Y, X).
+    Returns dict with ids, area, mean (n, C) f64, centroid_rne (n, ndim) int,
+    centroid (n, ndim) f64 -- axis order (z,) y, x."""
+    ids = list(np.unique(labels))[1:]            # analysis.py:80 drops the smallest value
+    c = img.shape[0]
+    nd = labels.ndim
+    mean = np.zeros((len(ids), c), dtype=np.float64)
+    cen = np.zeros((len(ids), nd), dtype=np.float64)
+    cen_r = np.zeros((len(ids), nd), dtype=np.int64)
+    area = np.zeros(len(ids), dtype=np.int64)
+    for i, obj in enumerate(ids):
+        sel = labels == obj
+        for ch in range(c):
+            mean[i, ch] = np.nanmean(a=img[ch], where=sel)      # analysis.py:98
+        coords = np.where(sel)                                    # analysis.py:164/169
+        area[i] = coords[0].size
+        for d in range(nd):
+            m = np.nanmean(coords[d])
+            cen[i, d] = m
+            cen_r[i, d] = round(m)                                # round-half-even on np.float64
+    return {"ids": np.asarray(ids, dtype=np.int64), "area": area, "mean": mean,
+            "centroid": cen, "centroid_rne": cen_r}
+
+
+def measure_labels(img: np.ndarray, labels: np.ndarray):
+    """Vectorised (np.bincount) restatement; bit-identical to the literal loop because
+    every sum is an exact integer below 2**53."""
+    lab = np.asarray(labels).astype(np.int64).ravel()
+    nb = int(lab.max()) + 1 if lab.size else 1
+    cnt = np.bincount(lab, minlength=nb)
+    present = np.nonzero(cnt)[0]
+    ids = present[1:]
+    c = img.shape[0]
+    nd = labels.ndim
+    mean = np.zeros((len(ids), c), dtype=np.float64)
+    for ch in range(c):
+        s = np.bincount(lab, weights=np.asarray(img[ch]).astype(np.float64).ravel(), minlength=nb)
+        mean[:, ch] = s[ids] / cnt[ids].astype(np.float64)
+    grids = np.indices(labels.shape)
+    cen = np.zeros((len(ids), nd), dtype=np.float64)
+    for d in range(nd):
+        s = np.bincount(lab, weights=grids[d].astype(np.float64).ravel(), minlength=nb)
+        cen[:, d] = s[ids] / cnt[ids].astype(np.float64)
+    cen_r = np.rint(cen).astype(np.int64)                         # rint == round-half-even
+    return {"ids": ids.astype(np.int64), "area": cnt[ids].astype(np.int64), "mean": mean,
+            "centroid": cen, "centroid_rne": cen_r}
+
+
+# --------------------------------------------------------------------------------------
+# whole path on one FOV (what bench.py's cpu_baseline times)
+# --------------------------------------------------------------------------------------
+
+
+def run_path(stack: np.ndarray, labels: np.ndarray, threshold: float, reg_ref: str = "first",
+             sigma: float = 0.0, size: int = 7):
+    """stack (T,C,Z,Y,X) u16, labels (T,Z,Y,X) u16 -> (registered stack, shifts, tables)."""
+    t, c, z, y, x = stack.shape
+    bg = np.empty_like(stack)
+    for f in range(t):
+        for ch in range(c):
+            for zz in range(z):
+                bg[f, ch, zz] = bg_smo(stack[f, ch, zz], threshold, sigma, size)[0]
+    reg, shifts = im_reg_stack(bg, 0, reg_ref)
+    tables = []
+    for f in range(t):
+        if z == 1:
+            tables.append(measure_labels(reg[f, :, 0], labels[f, 0]))
+        else:
+            tables.append(measure_labels(reg[f], labels[f]))
+    return reg, shifts, tables

@@ -1,0 +1,37 @@
+"""CPU: the oracle's measurement restatement against hand-computed answers and against its own
+literal (reference-loop) form.  analysis.py:80,98,164-173."""
+import numpy as np
+
+from oracle import ref_path as O
+from imageanalysis_pipeline_amd import synth
+
+
+def test_known_answer():
+    lab = np.zeros((4, 6), np.uint16)
+    lab[0:2, 0:2] = 2
+    lab[2:4, 3:6] = 5
+    img = np.arange(24, dtype=np.uint16).reshape(1, 4, 6) * 10
+    r = O.measure_labels(img, lab)
+    assert list(r["ids"]) == [2, 5]
+    assert list(r["area"]) == [4, 6]
+    assert r["mean"][0, 0] == (0 + 10 + 60 + 70) / 4
+    assert r["mean"][1, 0] == sum(10 * v for v in (15, 16, 17, 21, 22, 23)) / 6
+    assert r["centroid"].tolist() == [[0.5, 0.5], [2.5, 4.0]]
+    assert r["centroid_rne"].tolist() == [[0, 0], [2, 4]]     # round-half-even
+
+
+def test_vectorised_equals_literal():
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 65536, size=(2, 80, 120)).astype(np.uint16)
+    lab = synth.make_labels(80, 120, 9, seed=1)
+    a, b = O.measure_labels(img, lab), O.measure_labels_literal(img, lab)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_no_background_drops_smallest_label():
+    lab = np.full((4, 4), 3, np.uint16)
+    lab[:, 2:] = 8
+    img = np.ones((1, 4, 4), np.uint16)
+    assert list(O.measure_labels(img, lab)["ids"]) == [8]
+    assert list(O.measure_labels_literal(img, lab)["ids"]) == [8]
