@@ -1,0 +1,766 @@
+// Background subtraction and smoothing kernels (reference: pipeline/utility.py:213-270, 433-468).
+//
+// SMO background (utility.py:252-264):  per plane
+//   pass 1  smo_march_kernel<HIST>   u16 plane -> SMO value per pixel -> pixels whose SMO value is
+//           below the threshold go into a 65 536-bin histogram of the plane (+ 256-bin coarse one)
+//   pass 2  median_kernel            2*median from the two histograms (half-integers possible)
+//   pass 3  sub_med_kernel           out = max(2*v - med2, 0) >> 1   (== trunc(max(v - med, 0)))
+// Planes are processed in batches small enough that pass 3 re-reads its planes from the
+// 256 MiB Infinity Cache; algorithmic HBM bytes are 4 per pixel (one read + one write).
+//
+// smo_march_kernel: one WAVE marches down a strip of 256 columns (4 per lane; lanes 0 and 63
+// are halo, 248 columns are produced) x `band` rows.  Image rows live in registers, the
+// horizontal 7-tap sums use cross-lane shuffles (no LDS, no barriers), the vertical window is
+// a 7-slot register ring that is indexed statically by unrolling the march 7x.  scipy's
+// 'reflect' boundary of uniform_filter is reproduced by seeding / feeding the ring with the
+// mirrored rows and by mirroring the halo lanes' columns; np.gradient's one-sided edge
+// differences are reproduced as well.  The per-wave histogram is privatised in LDS over a
+// 1024-value window around the strip's first pixels (background is narrow); anything outside
+// goes straight to HBM atomics.
+#include "common.h"
+
+namespace iap {
+
+constexpr int SMO_COLS = 248;        // columns produced per wave
+constexpr int SMO_WIN = 1024;        // LDS histogram window (values) per wave
+constexpr int SMO_WAVES = 4;         // waves per workgroup (independent of each other)
+constexpr int HIST_FINE = 65536;
+constexpr int HIST_COARSE = 256;
+constexpr int HIST_WORDS = HIST_FINE + HIST_COARSE;
+
+enum { SMO_MODE_IMAGE = 0, SMO_MODE_HIST = 1 };
+
+struct f4 {
+  float v[4];
+};
+
+template <typename T>
+__device__ __forceinline__ f4 load_row4(const T* __restrict__ row, int x, bool ok);
+
+template <>
+__device__ __forceinline__ f4 load_row4<uint16_t>(const uint16_t* __restrict__ row, int x, bool ok) {
+  f4 r;
+  if (ok) {
+    uint2 w = *reinterpret_cast<const uint2*>(row + x);
+    r.v[0] = (float)(w.x & 0xffffu);
+    r.v[1] = (float)(w.x >> 16);
+    r.v[2] = (float)(w.y & 0xffffu);
+    r.v[3] = (float)(w.y >> 16);
+  } else {
+    r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0.f;
+  }
+  return r;
+}
+
+template <>
+__device__ __forceinline__ f4 load_row4<float>(const float* __restrict__ row, int x, bool ok) {
+  f4 r;
+  if (ok) {
+    float4 w = *reinterpret_cast<const float4*>(row + x);
+    r.v[0] = w.x;
+    r.v[1] = w.y;
+    r.v[2] = w.z;
+    r.v[3] = w.w;
+  } else {
+    r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0.f;
+  }
+  return r;
+}
+
+struct SmoGeom {
+  int Y, X;
+  int nstrips, nbands, band;
+  int tasks_per_plane;  // nstrips * nbands rounded up to a multiple of SMO_WAVES
+};
+
+// One row of horizontally 7-summed unit-gradient components from image rows v-1, v, v+1.
+__device__ __forceinline__ void smo_row(const f4& A, const f4& B, const f4& Cn, int v, int Y, int X, int xl,
+                                        int lane, bool left_strip, bool right_strip, f4& hy, f4& hx) {
+  float bl = __shfl_up(B.v[3], 1, 64);
+  float br = __shfl_down(B.v[0], 1, 64);
+  float ny[4], nx[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float gy = (v == 0) ? (Cn.v[i] - B.v[i]) : (v == Y - 1) ? (B.v[i] - A.v[i]) : 0.5f * (Cn.v[i] - A.v[i]);
+    float l = (i == 0) ? bl : B.v[i - 1];
+    float r = (i == 3) ? br : B.v[i + 1];
+    int x = xl + i;
+    float gx = (x == 0) ? (r - B.v[i]) : (x == X - 1) ? (B.v[i] - l) : 0.5f * (r - l);
+    float n2 = gy * gy + gx * gx;
+    float inv = n2 > 0.f ? rsqrtf(n2) : 0.f;
+    ny[i] = gy * inv;
+    nx[i] = gx * inv;
+  }
+  // neighbours' columns: left lane's cols 1..3, right lane's cols 0..2
+  float ly1 = __shfl_up(ny[1], 1, 64), ly2 = __shfl_up(ny[2], 1, 64), ly3 = __shfl_up(ny[3], 1, 64);
+  float lx1 = __shfl_up(nx[1], 1, 64), lx2 = __shfl_up(nx[2], 1, 64), lx3 = __shfl_up(nx[3], 1, 64);
+  float ry0 = __shfl_down(ny[0], 1, 64), ry1 = __shfl_down(ny[1], 1, 64), ry2 = __shfl_down(ny[2], 1, 64);
+  float rx0 = __shfl_down(nx[0], 1, 64), rx1 = __shfl_down(nx[1], 1, 64), rx2 = __shfl_down(nx[2], 1, 64);
+  if (left_strip && lane == 1) {  // columns -3,-2,-1 mirror columns 2,1,0 (scipy 'reflect')
+    ly1 = ny[2]; ly2 = ny[1]; ly3 = ny[0];
+    lx1 = nx[2]; lx2 = nx[1]; lx3 = nx[0];
+  }
+  if (right_strip && lane == 62) {  // columns X,X+1,X+2 mirror X-1,X-2,X-3
+    ry0 = ny[3]; ry1 = ny[2]; ry2 = ny[1];
+    rx0 = nx[3]; rx1 = nx[2]; rx2 = nx[1];
+  }
+  float sy = (ny[0] + ny[1]) + (ny[2] + ny[3]);
+  float sx = (nx[0] + nx[1]) + (nx[2] + nx[3]);
+  hy.v[0] = sy + ((ly1 + ly2) + ly3);
+  hy.v[1] = sy + ((ly2 + ly3) + ry0);
+  hy.v[2] = sy + (ly3 + (ry0 + ry1));
+  hy.v[3] = sy + ((ry0 + ry1) + ry2);
+  hx.v[0] = sx + ((lx1 + lx2) + lx3);
+  hx.v[1] = sx + ((lx2 + lx3) + rx0);
+  hx.v[2] = sx + (lx3 + (rx0 + rx1));
+  hx.v[3] = sx + ((rx0 + rx1) + rx2);
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(SMO_WAVES * 64) void smo_march_kernel(
+    const T* __restrict__ src, const uint16_t* __restrict__ orig, float* __restrict__ smo_out,
+    unsigned* __restrict__ hist, SmoGeom g, float thr2 /* (threshold*49)^2 */, float inv_area) {
+  __shared__ unsigned lds_fine[SMO_WAVES][SMO_WIN];
+  __shared__ unsigned lds_coarse[SMO_WAVES][HIST_COARSE];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int Y = g.Y, X = g.X;
+  const long long task_all = (long long)blockIdx.x * SMO_WAVES + wave;
+  const long long plane = task_all / g.tasks_per_plane;
+  const int task = (int)(task_all - plane * g.tasks_per_plane);
+  if (task >= g.nstrips * g.nbands) return;  // padding wave (no barriers in this kernel)
+  const int strip = task % g.nstrips;
+  const int bandi = task / g.nstrips;
+  const bool left_strip = strip == 0;
+  const bool right_strip = strip == g.nstrips - 1;
+  const int x0 = right_strip ? (X - 252) : (strip * SMO_COLS - 4);
+  const int own_lo = strip * SMO_COLS;
+  const int own_hi = right_strip ? X : own_lo + SMO_COLS;
+  const int xl = x0 + 4 * lane;                 // first column of this lane
+  const bool col_ok = xl >= 0 && xl + 3 < X;    // X % 4 == 0: a lane is entirely in or out
+  const int y0 = bandi * g.band;
+  const int yend = min(Y, y0 + g.band);
+  const bool top = y0 == 0;
+  const T* __restrict__ p = src + (size_t)plane * Y * X;
+  const uint16_t* __restrict__ po = orig ? orig + (size_t)plane * Y * X : nullptr;
+  unsigned* __restrict__ hfine = hist ? hist + (size_t)plane * HIST_WORDS : nullptr;
+  unsigned* __restrict__ hcoarse = hfine ? hfine + HIST_FINE : nullptr;
+
+  unsigned win_base = 0;
+  if (MODE == SMO_MODE_HIST) {
+    for (int i = lane; i < SMO_WIN; i += 64) lds_fine[wave][i] = 0;
+    for (int i = lane; i < HIST_COARSE; i += 64) lds_coarse[wave][i] = 0;
+    // window base from the minimum of the strip's first row (wave-uniform)
+    unsigned m = 0xffffu;
+    if (col_ok) {
+      uint2 w = *reinterpret_cast<const uint2*>(po + (size_t)y0 * X + xl);
+      m = min(min(w.x & 0xffffu, w.x >> 16), min(w.y & 0xffffu, w.y >> 16));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = min(m, (unsigned)__shfl_xor(m, o, 64));
+    win_base = m > 128u ? m - 128u : 0u;
+    if (win_base > (unsigned)(HIST_FINE - SMO_WIN)) win_base = HIST_FINE - SMO_WIN;
+  }
+
+  float ry[7][4], rx[7][4];  // vertical ring, statically indexed
+  const int vbase = y0 - 3;
+  const int vfirst = top ? 0 : vbase;
+  // rows v-1, v, v+1 of the row being computed, plus v+2 already in flight
+  f4 A = load_row4<T>(p + (size_t)max(vfirst - 1, 0) * X, xl, col_ok);
+  f4 B = load_row4<T>(p + (size_t)vfirst * X, xl, col_ok);
+  f4 Cn = load_row4<T>(p + (size_t)min(vfirst + 1, Y - 1) * X, xl, col_ok);
+  f4 Dn = load_row4<T>(p + (size_t)min(vfirst + 2, Y - 1) * X, xl, col_ok);
+
+  // Put virtual row v into ring slot PH (PH is a compile-time constant after unrolling).
+  // Rows Y, Y+1, Y+2 mirror Y-1, Y-2, Y-3, i.e. the slots filled 1, 3 and 5 steps ago.
+#define SMO_FILL(PH, VROW)                                                                              \
+  do {                                                                                               \
+    if ((VROW) < Y) {                                                                                   \
+      f4 hy_, hx_;                                                                                   \
+      smo_row(A, B, Cn, (VROW), Y, X, xl, lane, left_strip, right_strip, hy_, hx_);                     \
+      A = B;                                                                                         \
+      B = Cn;                                                                                        \
+      Cn = Dn;                                                                                       \
+      Dn = load_row4<T>(p + (size_t)min((VROW) + 3, Y - 1) * X, xl, col_ok);                            \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
+        ry[PH][i] = hy_.v[i];                                                                        \
+        rx[PH][i] = hx_.v[i];                                                                        \
+      }                                                                                              \
+    } else {                                                                                         \
+      const int j_ = (VROW) - Y;                                                                        \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
+        float ty_ = j_ == 0 ? ry[((PH) + 6) % 7][i] : (j_ == 1 ? ry[((PH) + 4) % 7][i] : ry[((PH) + 2) % 7][i]); \
+        float tx_ = j_ == 0 ? rx[((PH) + 6) % 7][i] : (j_ == 1 ? rx[((PH) + 4) % 7][i] : rx[((PH) + 2) % 7][i]); \
+        ry[PH][i] = ty_;                                                                             \
+        rx[PH][i] = tx_;                                                                             \
+      }                                                                                              \
+    }                                                                                                \
+  } while (0)
+
+  // ---- prologue: fill the ring with virtual rows vbase .. vbase+6
+#pragma unroll
+  for (int s = 0; s < 7; ++s) {
+    if (top && s < 3) {  // rows -3..-1: mirrored copies, filled below
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ry[s][i] = rx[s][i] = 0.f;
+      continue;
+    }
+    SMO_FILL(s, vbase + s);
+  }
+  if (top) {  // virtual rows -3,-2,-1 = rows 2,1,0
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ry[0][i] = ry[5][i]; rx[0][i] = rx[5][i];
+      ry[1][i] = ry[4][i]; rx[1][i] = rx[4][i];
+      ry[2][i] = ry[3][i]; rx[2][i] = rx[3][i];
+    }
+  }
+
+  auto emit = [&](int oy) {
+    float vy[4], vx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      vy[i] = ((ry[0][i] + ry[1][i]) + (ry[2][i] + ry[3][i])) + ((ry[4][i] + ry[5][i]) + ry[6][i]);
+      vx[i] = ((rx[0][i] + rx[1][i]) + (rx[2][i] + rx[3][i])) + ((rx[4][i] + rx[5][i]) + rx[6][i]);
+    }
+    const bool lane_own = lane >= 1 && lane <= 62 && xl >= own_lo && xl < own_hi;
+    if (MODE == SMO_MODE_IMAGE) {
+      if (lane_own) {
+        float4 o;
+        o.x = sqrtf(vy[0] * vy[0] + vx[0] * vx[0]) * inv_area;
+        o.y = sqrtf(vy[1] * vy[1] + vx[1] * vx[1]) * inv_area;
+        o.z = sqrtf(vy[2] * vy[2] + vx[2] * vx[2]) * inv_area;
+        o.w = sqrtf(vy[3] * vy[3] + vx[3] * vx[3]) * inv_area;
+        *reinterpret_cast<float4*>(smo_out + ((size_t)plane * Y + oy) * X + xl) = o;
+      }
+    } else {
+      if (lane_own) {
+        uint2 w = *reinterpret_cast<const uint2*>(po + (size_t)oy * X + xl);
+        unsigned px[4] = {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float s2 = vy[i] * vy[i] + vx[i] * vx[i];
+          if (s2 < thr2) {
+            unsigned val = px[i];
+            unsigned rel = val - win_base;
+            if (rel < (unsigned)SMO_WIN) {
+              atomicAdd(&lds_fine[wave][rel], 1u);
+              atomicAdd(&lds_coarse[wave][val >> 8], 1u);
+            } else {
+              atomicAdd(hfine + val, 1u);
+              atomicAdd(hcoarse + (val >> 8), 1u);
+            }
+          }
+        }
+      }
+    }
+  };
+
+  emit(y0);
+  // ---- march: output row oy needs virtual row oy+3, which goes into ring slot ph
+  int oy = y0 + 1;
+  while (oy < yend) {
+#pragma unroll
+    for (int ph = 0; ph < 7; ++ph) {
+      if (oy < yend) {
+        SMO_FILL(ph, oy + 3);
+        emit(oy);
+        ++oy;
+      }
+    }
+  }
+#undef SMO_FILL
+
+  if (MODE == SMO_MODE_HIST) {  // flush this wave's private histogram
+    for (int i = lane; i < SMO_WIN; i += 64) {
+      unsigned c = lds_fine[wave][i];
+      if (c) atomicAdd(hfine + win_base + i, c);
+    }
+    for (int i = lane; i < HIST_COARSE; i += 64) {
+      unsigned c = lds_coarse[wave][i];
+      if (c) atomicAdd(hcoarse + i, c);
+    }
+  }
+}
+
+// Generic fallback (any size, any odd `size`): one thread per pixel, brute force with
+// reflect indexing.  Only used when the marching kernel's shape constraints do not hold.
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+  int p = 2 * n;
+  i %= p;
+  if (i < 0) i += p;
+  return i >= n ? p - 1 - i : i;
+}
+
+template <typename T>
+__device__ __forceinline__ void unit_grad(const T* __restrict__ p, int y, int x, int Y, int X, float& ny,
+                                          float& nx) {
+  float c = (float)p[(size_t)y * X + x];
+  float gy, gx;
+  if (Y == 1) gy = 0.f;
+  else if (y == 0) gy = (float)p[(size_t)X + x] - c;
+  else if (y == Y - 1) gy = c - (float)p[(size_t)(y - 1) * X + x];
+  else gy = 0.5f * ((float)p[(size_t)(y + 1) * X + x] - (float)p[(size_t)(y - 1) * X + x]);
+  if (X == 1) gx = 0.f;
+  else if (x == 0) gx = (float)p[(size_t)y * X + 1] - c;
+  else if (x == X - 1) gx = c - (float)p[(size_t)y * X + x - 1];
+  else gx = 0.5f * ((float)p[(size_t)y * X + x + 1] - (float)p[(size_t)y * X + x - 1]);
+  float n2 = gy * gy + gx * gx;
+  float inv = n2 > 0.f ? rsqrtf(n2) : 0.f;
+  ny = gy * inv;
+  nx = gx * inv;
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void smo_generic_kernel(const T* __restrict__ src,
+                                                          const uint16_t* __restrict__ orig,
+                                                          float* __restrict__ smo_out,
+                                                          unsigned* __restrict__ hist, int Y, int X, int size,
+                                                          float thr2, float inv_area) {
+  long long plane = blockIdx.y;
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)Y * X) return;
+  int y = (int)(idx / X), x = (int)(idx - (long long)y * X);
+  const T* p = src + (size_t)plane * Y * X;
+  // scipy uniform_filter window for odd and even sizes: offsets -(size/2) .. size-1-size/2
+  int lo = -(size / 2), hi = size - 1 - size / 2;
+  float sy = 0.f, sx = 0.f;
+  for (int dy = lo; dy <= hi; ++dy) {
+    int yy = reflect_idx(y + dy, Y);
+    float rsy = 0.f, rsx = 0.f;
+    for (int dx = lo; dx <= hi; ++dx) {
+      int xx = reflect_idx(x + dx, X);
+      float ny, nx;
+      unit_grad<T>(p, yy, xx, Y, X, ny, nx);
+      rsy += ny;
+      rsx += nx;
+    }
+    sy += rsy;
+    sx += rsx;
+  }
+  float s2 = sy * sy + sx * sx;
+  if (MODE == SMO_MODE_IMAGE) {
+    smo_out[(size_t)plane * Y * X + idx] = sqrtf(s2) * inv_area;
+  } else if (s2 < thr2) {
+    unsigned val = orig[(size_t)plane * Y * X + idx];
+    unsigned* h = hist + (size_t)plane * HIST_WORDS;
+    atomicAdd(h + val, 1u);
+    atomicAdd(h + HIST_FINE + (val >> 8), 1u);
+  }
+}
+
+// ---- median from the two-level histogram: one workgroup per plane -------------------------
+__device__ __forceinline__ unsigned block_find_rank(unsigned cnt, unsigned long long rank, unsigned* sh,
+                                                    unsigned long long& before) {
+  // returns the index i (0..255) of the bin with prefix(i) <= rank < prefix(i)+cnt(i); `before` = prefix(i)
+  const int tid = threadIdx.x;
+  sh[tid] = cnt;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {  // Hillis-Steele inclusive scan
+    unsigned v = tid >= off ? sh[tid - off] : 0u;
+    __syncthreads();
+    sh[tid] += v;
+    __syncthreads();
+  }
+  unsigned incl = sh[tid];
+  unsigned excl = incl - cnt;
+  __shared__ unsigned found_i, found_before;
+  if (cnt && (unsigned long long)excl <= rank && rank < (unsigned long long)incl) {
+    found_i = tid;
+    found_before = excl;
+  }
+  __syncthreads();
+  unsigned r = found_i;
+  before = found_before;
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(256) void median_kernel(const unsigned* __restrict__ hist, int* __restrict__ med2,
+                                                     int* __restrict__ nbg, int* __restrict__ med2_user,
+                                                     int* __restrict__ nbg_user) {
+  __shared__ unsigned sh[256];
+  __shared__ unsigned total_s;
+  const int tid = threadIdx.x;
+  const unsigned* fine = hist + (size_t)blockIdx.x * HIST_WORDS;
+  const unsigned* coarse = fine + HIST_FINE;
+  unsigned c = coarse[tid];
+  // total
+  unsigned t = c;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+  if (tid == 0) total_s = 0;
+  __syncthreads();
+  if ((tid & 63) == 0) atomicAdd(&total_s, t);
+  __syncthreads();
+  const unsigned n = total_s;
+  int result = 0;
+  if (n > 0) {
+    unsigned long long k[2] = {(unsigned long long)(n - 1) / 2, (unsigned long long)n / 2};
+    for (int q = 0; q < 2; ++q) {
+      unsigned long long before;
+      unsigned cb = block_find_rank(c, k[q], sh, before);
+      unsigned f = fine[cb * 256 + tid];
+      unsigned long long before2;
+      unsigned fb = block_find_rank(f, k[q] - before, sh, before2);
+      result += (int)(cb * 256 + fb);
+    }
+  }
+  if (tid == 0) {
+    med2[blockIdx.x] = result;
+    nbg[blockIdx.x] = (int)n;
+    if (med2_user) med2_user[blockIdx.x] = result;
+    if (nbg_user) nbg_user[blockIdx.x] = (int)n;
+  }
+}
+
+// out = max(2 v - sub2[plane], 0) >> 1  : trunc(max(v - sub2/2, 0)), exact integer arithmetic
+__global__ __launch_bounds__(256) void sub_half_kernel(const uint16_t* __restrict__ in,
+                                                       uint16_t* __restrict__ out, long long plane_px,
+                                                       const int* __restrict__ sub2) {
+  const long long plane = blockIdx.y;
+  const int s2 = sub2[plane];
+  const uint16_t* pi = in + plane * plane_px;
+  uint16_t* po = out + plane * plane_px;
+  const long long nv = plane_px >> 3;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv;
+       i += (long long)gridDim.x * blockDim.x) {
+    u16x8 v = load8(pi + i * 8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      int d = 2 * (int)v.v[k] - s2;
+      v.v[k] = (uint16_t)(d > 0 ? (d >> 1) : 0);
+    }
+    store8(po + i * 8, v);
+  }
+  if (blockIdx.x == 0) {  // tail of planes whose pixel count is not a multiple of 8
+    long long i = nv * 8 + threadIdx.x;
+    if (i < plane_px) {
+      int d = 2 * (int)pi[i] - s2;
+      po[i] = (uint16_t)(d > 0 ? (d >> 1) : 0);
+    }
+  }
+}
+
+// ---- manual background: integer ROI sum per plane, bg = rint(sum / n) ----------------------
+__global__ __launch_bounds__(256) void roi_sum_kernel(const uint16_t* __restrict__ in, long long plane_px, int X,
+                                                      int r0, int c0, int r1, int c1,
+                                                      unsigned long long* __restrict__ sums) {
+  const long long plane = blockIdx.y;
+  const uint16_t* p = in + plane * plane_px;
+  const int w = c1 - c0 + 1;
+  const long long n = (long long)(r1 - r0 + 1) * w;
+  unsigned long long s = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    int r = (int)(i / w), c = (int)(i - (long long)r * w);
+    s += p[(size_t)(r0 + r) * X + c0 + c];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if ((threadIdx.x & 63) == 0 && s) atomicAdd(sums + plane, s);
+}
+
+__global__ void roi_bg_kernel(const unsigned long long* __restrict__ sums, long long n_roi, long long planes,
+                              int* __restrict__ bg2, int* __restrict__ bg_user) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= planes) return;
+  int bg = (int)rint((double)sums[i] / (double)n_roi);  // np.rint: round-half-even
+  bg2[i] = 2 * bg;
+  if (bg_user) bg_user[i] = bg;
+}
+
+// ---- scipy-style gaussian pre-smoothing for SMO(sigma > 0): plain, not on the default path ----
+template <typename T>
+__global__ __launch_bounds__(256) void gauss_reflect_kernel(const T* __restrict__ in, float* __restrict__ out,
+                                                            int Y, int X, int axis, int radius, float sigma) {
+  long long plane = blockIdx.y;
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)Y * X) return;
+  int y = (int)(idx / X), x = (int)(idx - (long long)y * X);
+  const T* p = in + (size_t)plane * Y * X;
+  float acc = 0.f, wsum = 0.f;
+  for (int k = -radius; k <= radius; ++k) {
+    float w = __expf(-0.5f * (float)(k * k) / (sigma * sigma));
+    int yy = axis == 0 ? reflect_idx(y + k, Y) : y;
+    int xx = axis == 1 ? reflect_idx(x + k, X) : x;
+    acc += w * (float)p[(size_t)yy * X + xx];
+    wsum += w;
+  }
+  out[(size_t)plane * Y * X + idx] = acc / wsum;
+}
+
+// ---- cv2.GaussianBlur semantics: LDS-staged separable tile, fp32, reflect-101, RNE+saturate ----
+constexpr int GB_TX = 64, GB_TY = 32, GB_MAXR = 31;
+
+__device__ __forceinline__ int reflect101_idx(int i, int n) {
+  if (n == 1) return 0;
+  int p = 2 * (n - 1);
+  i %= p;
+  if (i < 0) i += p;
+  return i >= n ? p - i : i;
+}
+
+struct GaussTaps {
+  float x[GB_MAXR + 1], y[GB_MAXR + 1];
+};
+
+__global__ __launch_bounds__(256) void gauss_blur_kernel(const uint16_t* __restrict__ in,
+                                                         uint16_t* __restrict__ out, int Y, int X, int rx,
+                                                         int ry, GaussTaps taps) {
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x;
+  const int wx = GB_TX + 2 * rx, hy = GB_TY + 2 * ry;
+  float* tile = lds;                 // hy x wx   input as float
+  float* rowp = lds + hy * wx;       // hy x GB_TX after the x pass
+  float* tx = rowp + hy * GB_TX;     // taps
+  float* ty = tx + (rx + 1);
+  const long long plane = blockIdx.z;
+  const int ox = blockIdx.x * GB_TX, oy = blockIdx.y * GB_TY;
+  const uint16_t* p = in + (size_t)plane * Y * X;
+  if (tid == 0) {
+    for (int i = 0; i <= rx; ++i) tx[i] = taps.x[i];
+    for (int i = 0; i <= ry; ++i) ty[i] = taps.y[i];
+  }
+  for (int i = tid; i < hy * wx; i += 256) {
+    int r = i / wx, c = i - r * wx;
+    int yy = reflect101_idx(oy + r - ry, Y), xx = reflect101_idx(ox + c - rx, X);
+    tile[i] = (float)p[(size_t)yy * X + xx];
+  }
+  __syncthreads();
+  for (int i = tid; i < hy * GB_TX; i += 256) {
+    int r = i / GB_TX, c = i - r * GB_TX;
+    const float* t = tile + r * wx + c + rx;
+    float s = __fmul_rn(tx[0], t[0]);
+    for (int k = 1; k <= rx; ++k) s = __fadd_rn(s, __fmul_rn(tx[k], __fadd_rn(t[-k], t[k])));
+    rowp[i] = s;
+  }
+  __syncthreads();
+  for (int i = tid; i < GB_TY * GB_TX; i += 256) {
+    int r = i / GB_TX, c = i - r * GB_TX;
+    int yy = oy + r, xx = ox + c;
+    if (yy < Y && xx < X) {
+      const float* t = rowp + (r + ry) * GB_TX + c;
+      float s = __fmul_rn(ty[0], t[0]);
+      for (int k = 1; k <= ry; ++k)
+        s = __fadd_rn(s, __fmul_rn(ty[k], __fadd_rn(t[-k * GB_TX], t[k * GB_TX])));
+      float r_ = rintf(s);
+      r_ = fminf(fmaxf(r_, 0.f), 65535.f);
+      out[(size_t)plane * Y * X + (size_t)yy * X + xx] = (uint16_t)r_;
+    }
+  }
+}
+
+static bool smo_fast_ok(int Y, int X, int size) { return size == 7 && X % 4 == 0 && X >= 248 && Y >= 8; }
+
+static SmoGeom smo_geom(int Y, int X, int band) {
+  SmoGeom g;
+  g.Y = Y;
+  g.X = X;
+  g.band = band;
+  g.nstrips = (X + SMO_COLS - 1) / SMO_COLS;
+  g.nbands = (Y + band - 1) / band;
+  int t = g.nstrips * g.nbands;
+  g.tasks_per_plane = (t + SMO_WAVES - 1) / SMO_WAVES * SMO_WAVES;
+  return g;
+}
+
+static int pick_band(int Y, int64_t n) {
+  // enough waves to fill 256 CUs x 16 waves while keeping the 6-row priming overhead small
+  int band = 128;
+  while (band > 32 && n * ((Y + band - 1) / band) * 9 < 256 * 16) band >>= 1;
+  return band;
+}
+
+template <typename T, int MODE>
+static int launch_smo(const T* src, const uint16_t* orig, float* smo_out, unsigned* hist, int64_t n, int Y,
+                      int X, int size, float threshold, hipStream_t st) {
+  double tscaled = (double)threshold * size * size;
+  float thr2 = (float)(tscaled * tscaled);
+  if (threshold <= 0) thr2 = 0.f;
+  float inv_area = 1.0f / (float)(size * size);
+  if (smo_fast_ok(Y, X, size)) {
+    SmoGeom g = smo_geom(Y, X, pick_band(Y, n));
+    long long blocks = (long long)n * g.tasks_per_plane / SMO_WAVES;
+    hipLaunchKernelGGL((smo_march_kernel<T, MODE>), dim3((unsigned)blocks), dim3(SMO_WAVES * 64), 0, st, src,
+                       orig, smo_out, hist, g, thr2, inv_area);
+  } else {
+    unsigned bx = (unsigned)(((long long)Y * X + 255) / 256);
+    hipLaunchKernelGGL((smo_generic_kernel<T, MODE>), dim3(bx, (unsigned)n), dim3(256), 0, st, src, orig,
+                       smo_out, hist, Y, X, size, thr2, inv_area);
+  }
+  IAP_LAUNCH_CHECK();
+  return IAP_OK;
+}
+
+template <typename T>
+static int launch_gauss_reflect(const T* in, float* tmp, float* out, int64_t n, int Y, int X, float sigma,
+                                hipStream_t st) {
+  int radius = (int)(4.0f * sigma + 0.5f);
+  unsigned bx = (unsigned)(((long long)Y * X + 255) / 256);
+  hipLaunchKernelGGL((gauss_reflect_kernel<T>), dim3(bx, (unsigned)n), dim3(256), 0, st, in, tmp, Y, X, 0,
+                     radius, sigma);
+  hipLaunchKernelGGL((gauss_reflect_kernel<float>), dim3(bx, (unsigned)n), dim3(256), 0, st,
+                     (const float*)tmp, out, Y, X, 1, radius, sigma);
+  IAP_LAUNCH_CHECK();
+  return IAP_OK;
+}
+
+constexpr int64_t BG_BATCH_BYTES = 96ll << 20;  // planes per batch: in + out traffic stays inside the MALL
+
+}  // namespace iap
+
+using namespace iap;
+
+static int check_plane_args(const char* fn, const void* in, const void* out, int64_t n, int Y, int X) {
+  IAP_REQUIRE(in && out, IAP_E_ARG, "%s: null pointer", fn);
+  IAP_REQUIRE(n > 0 && Y > 0 && X > 0, IAP_E_ARG, "%s: non-positive size (n=%lld Y=%d X=%d)", fn, (long long)n,
+              Y, X);
+  IAP_REQUIRE(aligned16(in) && aligned16(out), IAP_E_ALIGN, "%s: pointers must be 16-byte aligned", fn);
+  IAP_REQUIRE(n <= 0x7fffffff && (int64_t)Y * X < (1ll << 31), IAP_E_UNSUPPORTED, "%s: size too large", fn);
+  return IAP_OK;
+}
+
+extern "C" int iap_smo_image(const void* in, int in_kind, float* out, int64_t n, int Y, int X, float sigma,
+                             int size, void* stream) {
+  int rc = check_plane_args("iap_smo_image", in, out, n, Y, X);
+  if (rc) return rc;
+  IAP_REQUIRE(in_kind == 0 || in_kind == 1, IAP_E_ARG, "iap_smo_image: in_kind must be 0 (u16) or 1 (f32)");
+  IAP_REQUIRE(size >= 1 && size <= 63, IAP_E_ARG, "iap_smo_image: size must be in 1..63");
+  IAP_REQUIRE(size & 1, IAP_E_ARG, "iap_smo_image: size must be odd");
+  IAP_REQUIRE(sigma == 0.f, IAP_E_UNSUPPORTED,
+              "iap_smo_image: sigma > 0 needs scratch; use iap_bg_smo_u16 (which carries a workspace)");
+  IAP_REQUIRE(n <= 65535, IAP_E_UNSUPPORTED, "iap_smo_image: n must be <= 65535");
+  hipStream_t st = as_stream(stream);
+  if (in_kind == 0)
+    return launch_smo<uint16_t, SMO_MODE_IMAGE>((const uint16_t*)in, nullptr, out, nullptr, n, Y, X, size, 0.f,
+                                                st);
+  return launch_smo<float, SMO_MODE_IMAGE>((const float*)in, nullptr, out, nullptr, n, Y, X, size, 0.f, st);
+}
+
+static int64_t bg_batch_planes(int64_t n, int Y, int X) {
+  int64_t per = (int64_t)Y * X * 2;
+  int64_t b = BG_BATCH_BYTES / per;
+  if (b < 1) b = 1;
+  if (b > 256) b = 256;  // bounds the histogram workspace (257 KiB per plane in flight)
+  if (b > n) b = n;
+  return b;
+}
+
+extern "C" size_t iap_bg_smo_ws_bytes(int64_t n, int Y, int X) {
+  if (n <= 0 || Y <= 0 || X <= 0) return 0;
+  int64_t b = bg_batch_planes(n, Y, X);
+  // per batch plane: histogram words + med2 + nbg ; plus two float planes for sigma > 0
+  size_t per = (size_t)HIST_WORDS * 4 + 16 + (size_t)Y * X * 8;
+  return (size_t)b * per + 256;
+}
+
+extern "C" int iap_bg_smo_u16(const uint16_t* in, uint16_t* out, int64_t n, int Y, int X, float sigma, int size,
+                              float threshold, int32_t* med2_out, int32_t* nbg_out, void* ws, size_t ws_bytes,
+                              void* stream) {
+  int rc = check_plane_args("iap_bg_smo_u16", in, out, n, Y, X);
+  if (rc) return rc;
+  IAP_REQUIRE(size >= 1 && size <= 63, IAP_E_ARG, "iap_bg_smo_u16: size must be in 1..63");
+  IAP_REQUIRE(size & 1, IAP_E_ARG, "iap_bg_smo_u16: size must be odd");
+  IAP_REQUIRE(sigma >= 0.f, IAP_E_ARG, "iap_bg_smo_u16: sigma must be >= 0");
+  IAP_REQUIRE(ws && aligned16(ws), IAP_E_ARG, "iap_bg_smo_u16: workspace missing or not 16-byte aligned");
+  IAP_REQUIRE(ws_bytes >= iap_bg_smo_ws_bytes(n, Y, X), IAP_E_WS,
+              "iap_bg_smo_u16: workspace of %zu bytes, need %zu", ws_bytes, iap_bg_smo_ws_bytes(n, Y, X));
+  hipStream_t st = as_stream(stream);
+  const int64_t B = bg_batch_planes(n, Y, X);
+  const int64_t px = (int64_t)Y * X;
+  char* w = (char*)ws;
+  unsigned* hist = (unsigned*)w;
+  w += (size_t)B * HIST_WORDS * 4;
+  int* med2 = (int*)w;
+  w += (size_t)B * 8;
+  int* nbg = (int*)w;
+  w += (size_t)B * 8;
+  w = (char*)(((uintptr_t)w + 255) & ~(uintptr_t)255);
+  float* ftmp = (float*)w;
+  float* fsm = ftmp + (size_t)B * px;
+  for (int64_t p0 = 0; p0 < n; p0 += B) {
+    int64_t nb = n - p0 < B ? n - p0 : B;
+    const uint16_t* bin = in + p0 * px;
+    uint16_t* bout = out + p0 * px;
+    IAP_HIP(hipMemsetAsync(hist, 0, (size_t)nb * HIST_WORDS * 4, st));
+    if (sigma > 0.f) {
+      rc = launch_gauss_reflect<uint16_t>(bin, ftmp, fsm, nb, Y, X, sigma, st);
+      if (rc) return rc;
+      rc = launch_smo<float, SMO_MODE_HIST>(fsm, bin, nullptr, hist, nb, Y, X, size, threshold, st);
+    } else {
+      rc = launch_smo<uint16_t, SMO_MODE_HIST>(bin, bin, nullptr, hist, nb, Y, X, size, threshold, st);
+    }
+    if (rc) return rc;
+    hipLaunchKernelGGL(median_kernel, dim3((unsigned)nb), dim3(256), 0, st, hist, med2, nbg,
+                       med2_out ? med2_out + p0 : nullptr, nbg_out ? nbg_out + p0 : nullptr);
+    unsigned gx = (unsigned)((px / 8 + 255) / 256);
+    if (gx > 256) gx = 256;
+    if (gx == 0) gx = 1;
+    hipLaunchKernelGGL(sub_half_kernel, dim3(gx, (unsigned)nb), dim3(256), 0, st, bin, bout, (long long)px,
+                       (const int*)med2);
+    IAP_LAUNCH_CHECK();
+  }
+  return IAP_OK;
+}
+
+extern "C" int iap_bg_const_u16(const uint16_t* in, uint16_t* out, int64_t n, int Y, int X, int r0, int c0,
+                                int r1, int c1, int32_t* bg_out, void* ws, size_t ws_bytes, void* stream) {
+  int rc = check_plane_args("iap_bg_const_u16", in, out, n, Y, X);
+  if (rc) return rc;
+  IAP_REQUIRE(0 <= r0 && r0 <= r1 && r1 < Y && 0 <= c0 && c0 <= c1 && c1 < X, IAP_E_ARG,
+              "iap_bg_const_u16: ROI (%d,%d)-(%d,%d) outside the %dx%d plane", r0, c0, r1, c1, Y, X);
+  IAP_REQUIRE(ws && aligned16(ws) && ws_bytes >= (size_t)n * 16, IAP_E_WS,
+              "iap_bg_const_u16: workspace must hold n*16 bytes");
+  IAP_REQUIRE(n <= 65535, IAP_E_UNSUPPORTED, "iap_bg_const_u16: n must be <= 65535 per call");
+  hipStream_t st = as_stream(stream);
+  unsigned long long* sums = (unsigned long long*)ws;
+  int* bg2 = (int*)(sums + n);
+  IAP_HIP(hipMemsetAsync(sums, 0, (size_t)n * 8, st));
+  long long n_roi = (long long)(r1 - r0 + 1) * (c1 - c0 + 1);
+  unsigned gx = (unsigned)((n_roi + 255) / 256);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(roi_sum_kernel, dim3(gx, (unsigned)n), dim3(256), 0, st, in, (long long)Y * X, X, r0, c0, r1,
+                     c1, sums);
+  hipLaunchKernelGGL(roi_bg_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                     (const unsigned long long*)sums, n_roi, (long long)n, bg2, bg_out);
+  long long px = (long long)Y * X;
+  unsigned sx = (unsigned)((px / 8 + 255) / 256);
+  if (sx > 256) sx = 256;
+  if (sx == 0) sx = 1;
+  hipLaunchKernelGGL(sub_half_kernel, dim3(sx, (unsigned)n), dim3(256), 0, st, in, out, px, (const int*)bg2);
+  IAP_LAUNCH_CHECK();
+  return IAP_OK;
+}
+
+extern "C" int iap_gauss_blur_u16(const uint16_t* in, uint16_t* out, int64_t n, int Y, int X, int kx, int ky,
+                                  float sigma, void* stream) {
+  int rc = check_plane_args("iap_gauss_blur_u16", in, out, n, Y, X);
+  if (rc) return rc;
+  IAP_REQUIRE(in != out, IAP_E_ARG, "iap_gauss_blur_u16: in-place operation is not supported");
+  IAP_REQUIRE(kx >= 1 && ky >= 1 && (kx & 1) && (ky & 1) && kx <= 2 * GB_MAXR + 1 && ky <= 2 * GB_MAXR + 1,
+              IAP_E_ARG, "iap_gauss_blur_u16: kernel sizes must be odd and <= %d", 2 * GB_MAXR + 1);
+  IAP_REQUIRE(n <= 65535, IAP_E_UNSUPPORTED, "iap_gauss_blur_u16: n must be <= 65535 per call");
+  hipStream_t st = as_stream(stream);
+  // taps as cv2.getGaussianKernel(k, sigma, CV_32F); they ride to the kernel by value
+  GaussTaps h;
+  auto fill = [](int k, float sg, float* t) {
+    double s = sg > 0 ? sg : 0.3 * ((k - 1) * 0.5 - 1) + 0.8;
+    double w[2 * GB_MAXR + 1], sum = 0;
+    for (int i = 0; i < k; ++i) {
+      double x = i - (k - 1) * 0.5;
+      w[i] = exp(-(x * x) / (2.0 * s * s));
+      sum += w[i];
+    }
+    int r = (k - 1) / 2;
+    for (int i = 0; i <= r; ++i) t[i] = (float)(w[r + i] / sum);
+  };
+  fill(kx, sigma, h.x);
+  fill(ky, sigma, h.y);
+  int rx = (kx - 1) / 2, ry = (ky - 1) / 2;
+  size_t lds = ((size_t)(GB_TY + 2 * ry) * (GB_TX + 2 * rx) + (size_t)(GB_TY + 2 * ry) * GB_TX + rx + ry + 2) * 4;
+  dim3 grid((X + GB_TX - 1) / GB_TX, (Y + GB_TY - 1) / GB_TY, (unsigned)n);
+  hipLaunchKernelGGL(gauss_blur_kernel, grid, dim3(256), lds, st, in, out, Y, X, rx, ry, h);
+  IAP_LAUNCH_CHECK();
+  return IAP_OK;
+}

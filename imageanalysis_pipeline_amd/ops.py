@@ -109,3 +109,116 @@ def measure_labels(img: torch.Tensor, labels: torch.Tensor, n_labels: int | None
         out.append({"ids": ids.astype(np.int64), "area": area[f, ids], "mean": mean[f, ids],
                     "centroid": cen[f, ids][:, sl], "centroid_rne": cen_r[f, ids][:, sl]})
     return out
+
+
+# ----------------------------------------------------------------------------- background
+
+_ws_cache: dict = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only scratch tensor per device (the library itself never allocates)."""
+    key = str(device)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = None
+        _ws_cache[key] = None
+        ws = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def _planes(t: torch.Tensor):
+    if t.dim() < 2:
+        raise ValueError("need at least a (Y, X) plane")
+    y, x = t.shape[-2:]
+    n = t.numel() // (y * x)
+    return n, y, x
+
+
+def smo_image(planes: torch.Tensor, size: int = 7) -> torch.Tensor:
+    """SMO value (float32) of u16 or f32 planes (..., Y, X)  [smo.SMO.smo_image, utility.py:252]."""
+    _need_cuda(planes)
+    if planes.dtype == torch.uint16:
+        kind = 0
+    elif planes.dtype == torch.float32:
+        kind = 1
+    else:
+        raise TypeError("smo_image takes uint16 or float32 planes")
+    n, y, x = _planes(planes)
+    out = torch.empty(planes.shape, dtype=torch.float32, device=planes.device)
+    lib = _lib.load()
+    _lib.check(lib.iap_smo_image(planes.data_ptr(), kind, out.data_ptr(), n, y, x, 0.0, int(size), _stream()),
+               "iap_smo_image")
+    return out
+
+
+_thr_cache: dict = {}
+
+
+def smo_threshold(shape, sigma: float = 0.0, size: int = 7, seed: int = 0, q: float = 0.05, device="cuda") -> float:
+    """5 % quantile of the SMO value of a seeded normal-noise image (the null distribution the
+    reference draws unseeded in ``SMO(shape=...)``, utility.py:252).  The SMO image comes from
+    the HIP kernel; only the quantile selection of the copied-back values runs on the host."""
+    if sigma and sigma > 0:
+        raise NotImplementedError("null threshold with sigma > 0: pass an explicit threshold")
+    key = (tuple(shape), float(sigma), int(size), int(seed), float(q))
+    if key not in _thr_cache:
+        rng = np.random.default_rng(seed)
+        null = torch.from_numpy(rng.standard_normal(size=tuple(shape)).astype(np.float32)).to(device)
+        s = smo_image(null, size).cpu().numpy().astype(np.float64)
+        _thr_cache[key] = float(np.quantile(s, q))
+    return _thr_cache[key]
+
+
+def bg_smo(planes: torch.Tensor, threshold: float, sigma: float = 0.0, size: int = 7, out: torch.Tensor | None = None):
+    """utility.py:255-264 on u16 planes (..., Y, X); returns (out, med2 int32 (n,), nbg int32 (n,)).
+    ``out=planes`` runs in place (the reference overwrites its files)."""
+    _need_cuda(planes)
+    _u16(planes)
+    n, y, x = _planes(planes)
+    if out is None:
+        out = torch.empty_like(planes)
+    _need_cuda(out)
+    _u16(out)
+    if out.shape != planes.shape:
+        raise ValueError("out must have the shape of planes")
+    lib = _lib.load()
+    nb = lib.iap_bg_smo_ws_bytes(n, y, x)
+    ws = _workspace(nb, planes.device)
+    med2 = torch.empty(n, dtype=torch.int32, device=planes.device)
+    nbg = torch.empty(n, dtype=torch.int32, device=planes.device)
+    _lib.check(lib.iap_bg_smo_u16(planes.data_ptr(), out.data_ptr(), n, y, x, float(sigma), int(size),
+                                  float(threshold), med2.data_ptr(), nbg.data_ptr(), ws.data_ptr(), ws.numel(),
+                                  _stream()), "iap_bg_smo_u16")
+    return out, med2, nbg
+
+
+def bg_manual(planes: torch.Tensor, roi, out: torch.Tensor | None = None):
+    """utility.py:228-233: roi = (r0, c0, r1, c1) inclusive; returns (out, bg int32 (n,))."""
+    _need_cuda(planes)
+    _u16(planes)
+    n, y, x = _planes(planes)
+    if out is None:
+        out = torch.empty_like(planes)
+    r0, c0, r1, c1 = (int(v) for v in roi)
+    ws = _workspace(n * 16, planes.device)
+    bg = torch.empty(n, dtype=torch.int32, device=planes.device)
+    lib = _lib.load()
+    _lib.check(lib.iap_bg_const_u16(planes.data_ptr(), out.data_ptr(), n, y, x, r0, c0, r1, c1, bg.data_ptr(),
+                                    ws.data_ptr(), ws.numel(), _stream()), "iap_bg_const_u16")
+    return out, bg
+
+
+def gauss_blur(planes: torch.Tensor, ksize=(15, 15), sigma: float = 5.0) -> torch.Tensor:
+    """cv2.GaussianBlur(im, (kx, ky), sigma).astype(uint16) of utility.py:462 on u16 planes."""
+    _need_cuda(planes)
+    _u16(planes)
+    if type(ksize) is not tuple:
+        raise TypeError("The input 'blur_kernel' must be a tuple: (int,int)")
+    n, y, x = _planes(planes)
+    out = torch.empty_like(planes)
+    lib = _lib.load()
+    _lib.check(lib.iap_gauss_blur_u16(planes.data_ptr(), out.data_ptr(), n, y, x, int(ksize[0]), int(ksize[1]),
+                                      float(sigma), _stream()), "iap_gauss_blur_u16")
+    return out
