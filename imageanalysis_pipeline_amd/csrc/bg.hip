@@ -493,13 +493,6 @@ __global__ __launch_bounds__(256) void gauss_reflect_kernel(const T* __restrict_
 // ---- cv2.GaussianBlur semantics: LDS-staged separable tile, fp32, reflect-101, RNE+saturate ----
 constexpr int GB_TX = 64, GB_TY = 32, GB_MAXR = 31;
 
-__device__ __forceinline__ int reflect101_idx(int i, int n) {
-  if (n == 1) return 0;
-  int p = 2 * (n - 1);
-  i %= p;
-  if (i < 0) i += p;
-  return i >= n ? p - i : i;
-}
 
 struct GaussTaps {
   float x[GB_MAXR + 1], y[GB_MAXR + 1];

@@ -57,4 +57,13 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned n) {
   return base + (b >> 3);
 }
 
+// OpenCV BORDER_REFLECT_101 / scipy 'mirror' index: d c b | a b c d | c b a
+__device__ __forceinline__ int reflect101_idx(int i, int n) {
+  if (n == 1) return 0;
+  int p = 2 * (n - 1);
+  i %= p;
+  if (i < 0) i += p;
+  return i >= n ? p - i : i;
+}
+
 }  // namespace iap

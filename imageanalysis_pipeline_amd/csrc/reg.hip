@@ -1,0 +1,1035 @@
+// Registration: FFT cross-correlation shift estimate + fused apply-shift
+// (reference: pipeline/utility.py:274-430 im_reg, which calls pystackreg's TurboReg; the
+// estimator here is the FFT cross-power scheme north_star asks for).
+//
+// Estimate, per moving plane (all on device, no host round trip):
+//   K1 rows_r2c      u16 rows -> half spectrum, two real rows per complex FFT (LDS Stockham)
+//   K2 cols_xpower   column FFT, * conj-multiply with the reference spectrum (DC zeroed,
+//                    optional phase normalisation), write P, inverse column FFT in the same
+//                    LDS tile, write back in place
+//   K3 rows_c2r_argmax  inverse row FFT + wave-shuffle / LDS arg-max (correlation surface is
+//                    never written to HBM)
+//   K4 coarse_finish    arg-max over the per-workgroup partials -> signed integer shift
+//   K5 upsample_partial matrix-DFT of P on a 15x15 grid of 0.1 px offsets (partials per chunk)
+//   K6 upsample_finish  sum partials, arg-max, parabolic vertex -> (dy, dx) as f64
+// Apply: apply_shift_kernel -- separable 24-tap cardinal cubic B-spline FIR (the exact
+// prefilter+interpolation of scipy.ndimage.shift(order=3), truncated at 0.268^12) on LDS
+// tiles; mirror boundary, zero outside, clip, truncate to u16.  Integer shifts degenerate to
+// a delta kernel and are therefore exact copies.
+#include <math.h>
+#include "common.h"
+
+namespace iap {
+
+typedef float2 cf;
+
+__device__ __forceinline__ cf cmul(cf a, cf b) {
+  return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
+// multiply by -i (SIGN < 0, forward) or +i (inverse)
+template <int SIGN>
+__device__ __forceinline__ cf mul_i(cf a) {
+  return SIGN < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
+}
+
+__device__ __forceinline__ int padi(int i) { return i + (i >> 3); }
+
+template <int SIGN>
+__device__ __forceinline__ void dft2(cf* v) {
+  cf a = v[0], b = v[1];
+  v[0] = cadd(a, b);
+  v[1] = csub(a, b);
+}
+
+template <int SIGN>
+__device__ __forceinline__ void dft4(cf* v) {
+  cf e0 = cadd(v[0], v[2]), e1 = csub(v[0], v[2]);
+  cf o0 = cadd(v[1], v[3]), o1 = mul_i<SIGN>(csub(v[1], v[3]));
+  v[0] = cadd(e0, o0);
+  v[1] = cadd(e1, o1);
+  v[2] = csub(e0, o0);
+  v[3] = csub(e1, o1);
+}
+
+template <int SIGN>
+__device__ __forceinline__ void dft8(cf* v) {
+  const float h = 0.70710678118654752f;
+  cf a[4], b[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    a[n] = cadd(v[n], v[n + 4]);
+    b[n] = csub(v[n], v[n + 4]);
+  }
+  // b[n] *= W8^n, W8 = exp(SIGN * 2 pi i / 8)
+  {
+    cf t = b[1];  // (1 + SIGN i)/sqrt2
+    b[1] = SIGN < 0 ? make_float2(h * (t.x + t.y), h * (t.y - t.x)) : make_float2(h * (t.x - t.y), h * (t.y + t.x));
+    b[2] = mul_i<SIGN>(b[2]);
+    t = b[3];  // (-1 + SIGN i)/sqrt2
+    b[3] = SIGN < 0 ? make_float2(h * (t.y - t.x), -h * (t.x + t.y)) : make_float2(-h * (t.x + t.y), h * (t.x - t.y));
+  }
+  dft4<SIGN>(a);
+  dft4<SIGN>(b);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    v[2 * m] = a[m];
+    v[2 * m + 1] = b[m];
+  }
+}
+
+template <int R, int SIGN>
+__device__ __forceinline__ void dftR(cf* v) {
+  if constexpr (R == 8) dft8<SIGN>(v);
+  else if constexpr (R == 4) dft4<SIGN>(v);
+  else dft2<SIGN>(v);
+}
+
+// One Stockham radix-R pass over an N-point sequence held in LDS (padded index), done by
+// N/8 threads (8 points each).  tw[k] = exp(-2 pi i k / N).  Ends with a barrier.
+template <int N, int R, int SIGN, int Ns>
+__device__ __forceinline__ void fft_pass(cf* s, int j, const cf* __restrict__ tw) {
+  constexpr int NT = N / 8;
+  constexpr int NB = 8 / R;
+  cf v[NB][R];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int jj = j + b * NT;
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[b][r] = s[padi(jj + r * (N / R))];
+    if (Ns > 1) {
+      const int k = jj & (Ns - 1);
+      cf w1 = tw[k * (N / (Ns * R))];
+      if (SIGN > 0) w1.y = -w1.y;
+      if constexpr (R == 2) {
+        v[b][1] = cmul(v[b][1], w1);
+      } else {
+        cf w2 = cmul(w1, w1);
+        cf w3 = cmul(w2, w1);
+        v[b][1] = cmul(v[b][1], w1);
+        v[b][2] = cmul(v[b][2], w2);
+        v[b][3] = cmul(v[b][3], w3);
+        if constexpr (R == 8) {
+          cf w4 = cmul(w2, w2);
+          v[b][4] = cmul(v[b][4], w4);
+          v[b][5] = cmul(v[b][5], cmul(w4, w1));
+          v[b][6] = cmul(v[b][6], cmul(w4, w2));
+          v[b][7] = cmul(v[b][7], cmul(w4, w3));
+        }
+      }
+    }
+    dftR<R, SIGN>(v[b]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int jj = j + b * NT;
+    const int base = (jj / Ns) * (Ns * R) + (jj & (Ns - 1));
+#pragma unroll
+    for (int r = 0; r < R; ++r) s[padi(base + r * Ns)] = v[b][r];
+  }
+  __syncthreads();
+}
+
+template <int N, int SIGN, int Ns>
+__device__ __forceinline__ void fft_rec(cf* s, int j, const cf* __restrict__ tw) {
+  if constexpr (Ns < N) {
+    constexpr int rem = N / Ns;
+    constexpr int R = rem >= 8 ? 8 : rem;
+    fft_pass<N, R, SIGN, Ns>(s, j, tw);
+    fft_rec<N, SIGN, Ns * R>(s, j, tw);
+  }
+}
+
+// In-LDS N-point FFT; the data must be in place and the workgroup synchronised on entry.
+template <int N, int SIGN>
+__device__ __forceinline__ void fft_lds(cf* s, int j, const cf* __restrict__ tw) {
+  fft_rec<N, SIGN, 1>(s, j, tw);
+}
+
+template <int N>
+struct FftGeom {
+  static constexpr int NT = N / 8;                            // threads per FFT
+  static constexpr int PADN = N + N / 8;                      // padded LDS points per FFT
+  static constexpr int G = (256 / NT) > 1 ? (256 / NT) : 1;   // row FFTs per workgroup
+  static constexpr int TC = (8192 / N) < 16 ? (8192 / N) : 16;  // columns per workgroup
+  static constexpr int CS = PADN + 4;                         // LDS stride between columns
+};
+
+__global__ void twiddle_kernel(cf* tw, int n) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) {
+    double s, c;
+    sincospi(-2.0 * (double)k / (double)n, &s, &c);
+    tw[k] = make_float2((float)c, (float)s);
+  }
+}
+
+__device__ __forceinline__ float load_src(const void* __restrict__ p, int kind, size_t i) {
+  if (kind == 0) return (float)reinterpret_cast<const uint16_t*>(p)[i];
+  if (kind == 1) return (float)reinterpret_cast<const uint32_t*>(p)[i];
+  return reinterpret_cast<const float*>(p)[i];
+}
+
+// K1 ---------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_r2c_kernel(
+    const void* __restrict__ src, int kind, long long plane_stride, int srcX, int oy, int ox, float in_scale,
+    cf* __restrict__ F, long long F_stride, int Wp, const cf* __restrict__ tw) {
+  using Gm = FftGeom<N>;
+  extern __shared__ cf lds_c[];
+  const int g = threadIdx.x / Gm::NT, j = threadIdx.x % Gm::NT;
+  cf* s = lds_c + g * Gm::PADN;
+  const int pair = blockIdx.x * Gm::G + g;
+  const int ra = 2 * pair;
+  const size_t base = (size_t)blockIdx.y * plane_stride;
+  const size_t offa = base + (size_t)(oy + ra) * srcX + ox;
+  const size_t offb = offa + srcX;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    int n = j + m * Gm::NT;
+    s[padi(n)] = make_float2(load_src(src, kind, offa + n) * in_scale, load_src(src, kind, offb + n) * in_scale);
+  }
+  __syncthreads();
+  fft_lds<N, -1>(s, j, tw);
+  cf* Fa = F + (size_t)blockIdx.y * F_stride + (size_t)ra * Wp;
+  cf* Fb = Fa + Wp;
+  for (int k = j; k <= N / 2; k += Gm::NT) {
+    cf zk = s[padi(k)];
+    cf zn = s[padi((N - k) & (N - 1))];
+    Fa[k] = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+    Fb[k] = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+  }
+}
+
+// K2 ---------------------------------------------------------------------------------------
+// mode 0: forward column FFT in place (reference spectrum).
+// mode 1: forward FFT, P = G * conj(F) * scale (DC = 0, optional /|P|), store P to R (if R),
+//         inverse FFT, store back to F in place.
+template <int N>
+__global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::NT) void cols_kernel(
+    cf* __restrict__ F, long long F_stride, const cf* __restrict__ Gref, cf* __restrict__ R, long long R_stride,
+    int Wp, const cf* __restrict__ tw, int mode, int normalize, float scale) {
+  using Gm = FftGeom<N>;
+  constexpr int NTH = Gm::TC * Gm::NT;
+  extern __shared__ cf lds_c[];
+  const int tid = threadIdx.x;
+  const int c = tid / Gm::NT, j = tid % Gm::NT;
+  cf* s = lds_c + c * Gm::CS;
+  const int v0 = xcd_remap(blockIdx.x, gridDim.x) * Gm::TC;
+  cf* Ff = F + (size_t)blockIdx.y * F_stride;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    int idx = tid + m * NTH;
+    int cc = idx % Gm::TC, u = idx / Gm::TC;
+    lds_c[cc * Gm::CS + padi(u)] = Ff[(size_t)u * Wp + v0 + cc];
+  }
+  __syncthreads();
+  fft_lds<N, -1>(s, j, tw);
+  if (mode == 1) {
+    cf* Rf = R ? R + (size_t)blockIdx.y * R_stride : nullptr;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      int idx = tid + m * NTH;
+      int cc = idx % Gm::TC, u = idx / Gm::TC;
+      cf g = lds_c[cc * Gm::CS + padi(u)];
+      cf f = Gref[(size_t)u * Wp + v0 + cc];
+      cf p = make_float2((f.x * g.x + f.y * g.y) * scale, (f.y * g.x - f.x * g.y) * scale);
+      if (normalize) {
+        float m2 = p.x * p.x + p.y * p.y;
+        float inv = m2 > 0.f ? rsqrtf(m2) : 0.f;
+        p.x *= inv;
+        p.y *= inv;
+      }
+      if (u == 0 && v0 + cc == 0) p = make_float2(0.f, 0.f);
+      if (Rf) Rf[(size_t)u * Wp + v0 + cc] = p;
+      lds_c[cc * Gm::CS + padi(u)] = p;
+    }
+    __syncthreads();
+    fft_lds<N, +1>(s, j, tw);
+  }
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    int idx = tid + m * NTH;
+    int cc = idx % Gm::TC, u = idx / Gm::TC;
+    Ff[(size_t)u * Wp + v0 + cc] = lds_c[cc * Gm::CS + padi(u)];
+  }
+}
+
+// K3 ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void amax_take(float& v, int& i, float ov, int oi) {
+  if (ov > v || (ov == v && oi < i)) {
+    v = ov;
+    i = oi;
+  }
+}
+
+__device__ __forceinline__ void block_argmax(float& v, int& i, float* shv, int* shi) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float ov = __shfl_down(v, o, 64);
+    int oi = __shfl_down(i, o, 64);
+    amax_take(v, i, ov, oi);
+  }
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    shv[w] = v;
+    shi[w] = i;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < nw; ++k) amax_take(v, i, shv[k], shi[k]);
+  }
+}
+
+template <int N>
+__global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_c2r_argmax_kernel(
+    const cf* __restrict__ Q, long long Q_stride, int Wp, const cf* __restrict__ tw, float* __restrict__ pval,
+    int* __restrict__ pidx) {
+  using Gm = FftGeom<N>;
+  extern __shared__ cf lds_c[];
+  __shared__ float shv[16];
+  __shared__ int shi[16];
+  const int g = threadIdx.x / Gm::NT, j = threadIdx.x % Gm::NT;
+  cf* s = lds_c + g * Gm::PADN;
+  const int pair = blockIdx.x * Gm::G + g;
+  const int ra = 2 * pair, rb = ra + 1;
+  const cf* Qa = Q + (size_t)blockIdx.y * Q_stride + (size_t)ra * Wp;
+  const cf* Qb = Qa + Wp;
+  for (int k = j; k <= N / 2; k += Gm::NT) {
+    cf a = Qa[k], b = Qb[k];
+    if (k == 0 || k == N / 2) {  // c2r convention: the imaginary parts of the self-conjugate bins are ignored
+      a.y = 0.f;
+      b.y = 0.f;
+    }
+    s[padi(k)] = make_float2(a.x - b.y, a.y + b.x);
+    if (k > 0 && k < N / 2) s[padi(N - k)] = make_float2(a.x + b.y, b.x - a.y);
+  }
+  __syncthreads();
+  fft_lds<N, +1>(s, j, tw);
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    int n = j + m * Gm::NT;
+    cf z = s[padi(n)];
+    amax_take(bv, bi, z.x, ra * N + n);
+    amax_take(bv, bi, z.y, rb * N + n);
+  }
+  block_argmax(bv, bi, shv, shi);
+  if (threadIdx.x == 0) {
+    pval[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = bv;
+    pidx[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = bi;
+  }
+}
+
+// K4 ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void coarse_finish_kernel(const float* __restrict__ pval,
+                                                            const int* __restrict__ pidx, int nparts, int Py, int Px,
+                                                            int2* __restrict__ coarse, double* __restrict__ shifts,
+                                                            int write_shifts) {
+  __shared__ float shv[16];
+  __shared__ int shi[16];
+  float bv = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int k = threadIdx.x; k < nparts; k += 256)
+    amax_take(bv, bi, pval[(size_t)blockIdx.x * nparts + k], pidx[(size_t)blockIdx.x * nparts + k]);
+  block_argmax(bv, bi, shv, shi);
+  if (threadIdx.x == 0) {
+    if (bi == 0x7fffffff) bi = 0;  // all-NaN / empty surface: no shift
+    int py = bi / Px, px = bi - py * Px;
+    int sy = py > Py / 2 ? py - Py : py;
+    int sx = px > Px / 2 ? px - Px : px;
+    coarse[blockIdx.x] = make_int2(sy, sx);
+    if (write_shifts) {
+      shifts[2 * blockIdx.x] = (double)sy;
+      shifts[2 * blockIdx.x + 1] = (double)sx;
+    }
+  }
+}
+
+// K5 ---------------------------------------------------------------------------------------
+constexpr int UP_N = 15;       // grid points per axis: offsets -0.7 .. 0.7
+constexpr int UP_HALF = 7;
+constexpr float UP_STEP = 0.1f;
+constexpr int UP_UB = 64;      // spectrum rows per workgroup
+
+__device__ __forceinline__ cf unit_phase(int freq, int ishift, int n, float frac_shift) {
+  // exp(2 pi i * freq * (ishift + frac_shift) / n); the integer part is reduced exactly
+  int a = (int)(((long long)freq * ishift) % n);
+  float rev = (float)a / (float)n + (float)freq * frac_shift / (float)n;
+  float sn, cs;
+  sincospif(2.0f * rev, &sn, &cs);
+  return make_float2(cs, sn);
+}
+
+__global__ __launch_bounds__(256) void upsample_partial_kernel(const cf* __restrict__ R, long long R_stride, int Wp,
+                                                               int Py, int Px, int ncg,
+                                                               const int2* __restrict__ coarse,
+                                                               float* __restrict__ part) {
+  __shared__ cf ey[UP_UB][UP_N];
+  __shared__ cf Tl[UP_N][256 + 1];
+  __shared__ cf ex[256][UP_N];
+  const int tid = threadIdx.x;
+  const int cg = blockIdx.x % ncg, uc = blockIdx.x / ncg;
+  const int frame = blockIdx.y;
+  const int2 cs = coarse[frame];
+  const int u0 = uc * UP_UB;
+  for (int i = tid; i < UP_UB * UP_N; i += 256) {
+    int ul = i / UP_N, jq = i - ul * UP_N;
+    int u = u0 + ul;
+    int fu = u < Py / 2 ? u : u - Py;
+    ey[ul][jq] = unit_phase(fu, cs.x, Py, (float)(jq - UP_HALF) * UP_STEP);
+  }
+  const int v = cg * 256 + tid;
+  const bool valid = v <= Px / 2;
+  const int fv = v < Px / 2 ? v : v - Px;
+#pragma unroll
+  for (int k = 0; k < UP_N; ++k) ex[tid][k] = unit_phase(fv, 0, Px, (float)(k - UP_HALF) * UP_STEP);
+  __syncthreads();
+  cf acc[UP_N];
+#pragma unroll
+  for (int jq = 0; jq < UP_N; ++jq) acc[jq] = make_float2(0.f, 0.f);
+  const cf* Rp = R + (size_t)frame * R_stride + (size_t)u0 * Wp + v;
+  if (valid) {
+    for (int ul = 0; ul < UP_UB; ++ul) {
+      cf r = Rp[(size_t)ul * Wp];
+#pragma unroll
+      for (int jq = 0; jq < UP_N; ++jq) {
+        cf e = ey[ul][jq];
+        acc[jq].x = fmaf(r.x, e.x, fmaf(-r.y, e.y, acc[jq].x));
+        acc[jq].y = fmaf(r.x, e.y, fmaf(r.y, e.x, acc[jq].y));
+      }
+    }
+  }
+  // fold the column weight (Hermitian doubling) and the integer-shift phase into T
+  float w = (!valid) ? 0.f : ((v == 0 || v == Px / 2) ? 1.f : 2.f);
+  cf ph = unit_phase(fv, cs.y, Px, 0.f);
+  ph.x *= w;
+  ph.y *= w;
+#pragma unroll
+  for (int jq = 0; jq < UP_N; ++jq) Tl[jq][tid] = cmul(acc[jq], ph);
+  __syncthreads();
+  if (tid < UP_N * UP_N) {
+    const int jq = tid / UP_N, k = tid - jq * UP_N;
+    float sum = 0.f;
+    for (int vv = 0; vv < 256; ++vv) {
+      cf t = Tl[jq][vv], e = ex[vv][k];
+      sum = fmaf(t.x, e.x, fmaf(-t.y, e.y, sum));
+    }
+    part[((size_t)frame * gridDim.x + blockIdx.x) * (UP_N * UP_N) + tid] = sum;
+  }
+}
+
+// K6 ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double parabola(double vm, double v0, double vp) {
+  double den = vm - 2.0 * v0 + vp;
+  if (!(den < 0.0)) return 0.0;
+  double d = 0.5 * (vm - vp) / den;
+  return fmin(0.5, fmax(-0.5, d));
+}
+
+__global__ __launch_bounds__(256) void upsample_finish_kernel(const float* __restrict__ part, int nchunks,
+                                                              const int2* __restrict__ coarse,
+                                                              double* __restrict__ shifts) {
+  __shared__ float V[UP_N * UP_N];
+  const int frame = blockIdx.x, tid = threadIdx.x;
+  if (tid < UP_N * UP_N) {
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += part[((size_t)frame * nchunks + c) * (UP_N * UP_N) + tid];
+    V[tid] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int best = 0;
+    float bv = V[0];
+    for (int i = 1; i < UP_N * UP_N; ++i)
+      if (V[i] > bv) {
+        bv = V[i];
+        best = i;
+      }
+    int iy = best / UP_N, ix = best - iy * UP_N;
+    int2 cs = coarse[frame];
+    double cy = (double)cs.x + (double)(iy - UP_HALF) * 0.1;
+    double cx = (double)cs.y + (double)(ix - UP_HALF) * 0.1;
+    if (iy > 0 && iy < UP_N - 1)
+      cy += 0.1 * parabola((double)V[(iy - 1) * UP_N + ix], (double)V[best], (double)V[(iy + 1) * UP_N + ix]);
+    if (ix > 0 && ix < UP_N - 1)
+      cx += 0.1 * parabola((double)V[iy * UP_N + ix - 1], (double)V[best], (double)V[iy * UP_N + ix + 1]);
+    shifts[2 * frame] = cy;
+    shifts[2 * frame + 1] = cx;
+  }
+}
+
+// MIP / plane sums -------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mip_kernel(const uint16_t* __restrict__ in, long long in_stride,
+                                                  uint16_t* __restrict__ out, int Z, long long px) {
+  const long long item = blockIdx.y;
+  const uint16_t* p = in + item * in_stride;
+  uint16_t* o = out + item * px;
+  const long long nv = px >> 3;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv;
+       i += (long long)gridDim.x * blockDim.x) {
+    u16x8 m = load8(p + i * 8);
+    for (int z = 1; z < Z; ++z) {
+      u16x8 v = load8(p + z * px + i * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) m.v[k] = v.v[k] > m.v[k] ? v.v[k] : m.v[k];
+    }
+    store8(o + i * 8, m);
+  }
+  if (blockIdx.x == 0) {
+    long long i = nv * 8 + threadIdx.x;
+    if (i < px) {
+      uint16_t m = p[i];
+      for (int z = 1; z < Z; ++z) m = p[z * px + i] > m ? p[z * px + i] : m;
+      o[i] = m;
+    }
+  }
+}
+
+// sum[i] += sum over n planes (stride apart) of plane[i]
+__global__ __launch_bounds__(256) void accum_planes_kernel(const uint16_t* __restrict__ in, long long stride,
+                                                           long long n, long long px, uint32_t* __restrict__ sum) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < px;
+       i += (long long)gridDim.x * blockDim.x) {
+    uint32_t s = sum[i];
+    for (long long k = 0; k < n; ++k) s += in[k * stride + i];
+    sum[i] = s;
+  }
+}
+
+// Apply ------------------------------------------------------------------------------------
+constexpr int AP_R = 11;             // taps k = -AP_R .. AP_R+1
+constexpr int AP_TAPS = 2 * AP_R + 2;  // 24
+constexpr int AP_TX = 64, AP_TY = 64;
+constexpr int AP_W = AP_TX + AP_TAPS;  // staged tile width (88; one column spare)
+constexpr int AP_H = AP_TY + AP_TAPS;
+
+struct AxisParams {
+  int sh;      // integer part: source index = i + sh + k
+  int lo, hi;  // output indices with a source coordinate inside [0, n-1]
+};
+
+__device__ __forceinline__ double bspline3(double t) {
+  t = fabs(t);
+  if (t < 1.0) return 2.0 / 3.0 - t * t + 0.5 * t * t * t;
+  if (t < 2.0) {
+    double q = 2.0 - t;
+    return q * q * q / 6.0;
+  }
+  return 0.0;
+}
+
+// tap k (index 0..23 <-> k = -11..12) of the cardinal cubic spline kernel at fraction `frac`
+__device__ __forceinline__ float cardinal_tap(int ti, double frac) {
+  const double z1 = -0.26794919243112270647;  // sqrt(3) - 2
+  const double c0 = -6.0 * z1 / (1.0 - z1 * z1);
+  if (frac == 0.0) return ti == AP_R ? 1.f : 0.f;  // integer shift: exact delta
+  int k = ti - AP_R;
+  double h = 0.0;
+  for (int jq = -1; jq <= 2; ++jq) {
+    int e = k - jq;
+    if (e < 0) e = -e;
+    double zp = 1.0;
+    for (int q = 0; q < e; ++q) zp *= z1;
+    h += bspline3(frac - (double)jq) * c0 * zp;
+  }
+  return (float)h;
+}
+
+__device__ __forceinline__ AxisParams axis_params(double d, int n, double& frac) {
+  AxisParams a;
+  double nf = floor(-d);
+  frac = -d - nf;
+  a.sh = (int)nf;
+  // i - d >= 0  <=> i >= d ; i - d <= n-1 <=> i <= n-1+d
+  double lo = ceil(d), hi = floor((double)(n - 1) + d);
+  a.lo = lo < 0.0 ? 0 : (lo > (double)n ? n : (int)lo);
+  a.hi = hi > (double)(n - 1) ? n - 1 : (hi < -1.0 ? -1 : (int)hi);
+  return a;
+}
+
+__global__ __launch_bounds__(256) void apply_shift_kernel(const uint16_t* __restrict__ in,
+                                                          uint16_t* __restrict__ out, long long planes_per_frame,
+                                                          int Y, int X, const double* __restrict__ shifts) {
+  __shared__ float tile[AP_H][AP_W + 1];
+  __shared__ float rowp[AP_H][AP_TX + 1];
+  __shared__ float tapy[AP_TAPS], tapx[AP_TAPS];
+  __shared__ AxisParams pay, pax;
+  const int tid = threadIdx.x;
+  const long long plane = blockIdx.z;
+  const long long frame = plane / planes_per_frame;
+  const double dy = shifts[2 * frame], dx = shifts[2 * frame + 1];
+  if (tid < 2 * AP_TAPS) {
+    bool isy = tid < AP_TAPS;
+    double frac;
+    AxisParams a = axis_params(isy ? dy : dx, isy ? Y : X, frac);
+    float h = cardinal_tap(isy ? tid : tid - AP_TAPS, frac);
+    if (isy) tapy[tid] = h;
+    else tapx[tid - AP_TAPS] = h;
+    if (tid == 0) pay = a;
+    if (tid == AP_TAPS) pax = a;
+  }
+  __syncthreads();
+  const int ox = blockIdx.x * AP_TX, oy = blockIdx.y * AP_TY;
+  const uint16_t* p = in + (size_t)plane * Y * X;
+  uint16_t* po = out + (size_t)plane * Y * X;
+  const AxisParams ay = pay, ax = pax;
+  // whole tile outside the valid range -> zeros
+  // stage the source tile (mirror boundary = the spline prefilter's boundary condition)
+  for (int i = tid; i < AP_H * AP_W; i += 256) {
+    int r = i / AP_W, c = i - r * AP_W;
+    int yy = reflect101_idx(oy + r + ay.sh - AP_R, Y);
+    int xx = reflect101_idx(ox + c + ax.sh - AP_R, X);
+    tile[r][c] = (float)p[(size_t)yy * X + xx];
+  }
+  __syncthreads();
+  // x pass: AP_H rows x AP_TX outputs; each thread 8 consecutive outputs of one row
+  for (int i = tid; i < AP_H * (AP_TX / 8); i += 256) {
+    int r = i / (AP_TX / 8), c0 = (i - r * (AP_TX / 8)) * 8;
+    float acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+    float win[8 + AP_TAPS - 1];
+#pragma unroll
+    for (int q = 0; q < 8 + AP_TAPS - 1; ++q) win[q] = tile[r][c0 + q];
+#pragma unroll
+    for (int k = 0; k < AP_TAPS; ++k) {
+      float t = tapx[k];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] = fmaf(t, win[q + k], acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) rowp[r][c0 + q] = acc[q];
+  }
+  __syncthreads();
+  // y pass: each thread one column, 16 consecutive output rows
+  {
+    const int c = tid & 63, r0 = (tid >> 6) * 16;
+    float acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    float win[16 + AP_TAPS - 1];
+#pragma unroll
+    for (int q = 0; q < 16 + AP_TAPS - 1; ++q) win[q] = rowp[r0 + q][c];
+#pragma unroll
+    for (int k = 0; k < AP_TAPS; ++k) {
+      float t = tapy[k];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = fmaf(t, win[q + k], acc[q]);
+    }
+    const int xx = ox + c;
+    if (xx < X) {
+      const bool xin = xx >= ax.lo && xx <= ax.hi;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        int yy = oy + r0 + q;
+        if (yy < Y) {
+          float v = acc[q];
+          bool inside = xin && yy >= ay.lo && yy <= ay.hi;
+          v = inside ? fminf(fmaxf(v, 0.f), 65535.f) : 0.f;
+          po[(size_t)yy * X + xx] = (uint16_t)v;  // truncation toward zero
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+
+static int fft_window(int n) {
+  int p = 1;
+  while (p * 2 <= n) p *= 2;
+  return p > 4096 ? 4096 : p;
+}
+
+struct RegPlan {
+  int Y, X, Py, Px, oy, ox, Wp;
+  size_t spec;      // complex elements per spectrum
+  int row_blocks;   // workgroups of the row kernels per frame (= arg-max partials)
+  int col_blocks;
+  int ncg, nuc;     // upsample chunks: column groups x row chunks
+};
+
+template <int N>
+static int rows_G() { return FftGeom<N>::G; }
+
+static int geom_rows_G(int N) {
+  int nt = N / 8;
+  int g = 256 / nt;
+  return g > 1 ? g : 1;
+}
+static int geom_TC(int N) { return (8192 / N) < 16 ? (8192 / N) : 16; }
+
+static bool make_plan(int Y, int X, RegPlan& p) {
+  p.Y = Y;
+  p.X = X;
+  p.Py = fft_window(Y);
+  p.Px = fft_window(X);
+  if (p.Py < 64 || p.Px < 64) return false;
+  p.oy = (Y - p.Py) / 2;
+  p.ox = (X - p.Px) / 2;
+  p.Wp = (p.Px / 2 + 1 + 15) / 16 * 16;
+  p.spec = (size_t)p.Py * p.Wp;
+  p.row_blocks = p.Py / 2 / geom_rows_G(p.Px);
+  p.col_blocks = p.Wp / geom_TC(p.Py);
+  p.ncg = (p.Px / 2 + 1 + 255) / 256;
+  p.nuc = p.Py / UP_UB;
+  return true;
+}
+
+struct RegWs {
+  cf *tw_x, *tw_y, *refspec, *F, *R;
+  float* pval;
+  int* pidx;
+  int2* coarse;
+  float* upart;
+  uint16_t *mip, *mip_ref;
+  uint32_t* sum;
+  int batch;
+};
+
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static size_t reg_fixed_bytes(const RegPlan& p) {
+  return align256(4096 * 8) * 2 + align256(p.spec * 8) + align256((size_t)p.Y * p.X * 2) +
+         align256((size_t)p.Y * p.X * 4) + 1024;
+}
+static size_t reg_frame_bytes(const RegPlan& p, int Z) {
+  size_t b = 2 * align256(p.spec * 8) + 2 * align256((size_t)p.row_blocks * 4) + 256 +
+             align256((size_t)p.ncg * p.nuc * UP_N * UP_N * 4);
+  if (Z > 1) b += align256((size_t)p.Y * p.X * 2);
+  return b;
+}
+
+static bool carve(void* ws, size_t bytes, const RegPlan& p, int Z, RegWs& w) {
+  size_t fixed = reg_fixed_bytes(p), per = reg_frame_bytes(p, Z);
+  if (bytes < fixed + per) return false;
+  int batch = (int)((bytes - fixed) / per);
+  if (batch > 4096) batch = 4096;
+  w.batch = batch;
+  char* c = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  auto take = [&](size_t n) {
+    char* r = c;
+    c += align256(n);
+    return r;
+  };
+  w.tw_x = (cf*)take(4096 * 8);
+  w.tw_y = (cf*)take(4096 * 8);
+  w.refspec = (cf*)take(p.spec * 8);
+  w.mip_ref = (uint16_t*)take((size_t)p.Y * p.X * 2);
+  w.sum = (uint32_t*)take((size_t)p.Y * p.X * 4);
+  w.F = (cf*)take((size_t)batch * align256(p.spec * 8));
+  w.R = (cf*)take((size_t)batch * align256(p.spec * 8));
+  w.pval = (float*)take((size_t)batch * p.row_blocks * 4);
+  w.pidx = (int*)take((size_t)batch * p.row_blocks * 4);
+  w.coarse = (int2*)take((size_t)batch * 8);
+  w.upart = (float*)take((size_t)batch * p.ncg * p.nuc * UP_N * UP_N * 4);
+  w.mip = Z > 1 ? (uint16_t*)take((size_t)batch * p.Y * p.X * 2) : nullptr;
+  return true;
+}
+
+#define IAP_FOR_N(N_, BODY)          \
+  switch (N_) {                      \
+    case 64: { constexpr int N = 64; BODY; } break;      \
+    case 128: { constexpr int N = 128; BODY; } break;    \
+    case 256: { constexpr int N = 256; BODY; } break;    \
+    case 512: { constexpr int N = 512; BODY; } break;    \
+    case 1024: { constexpr int N = 1024; BODY; } break;  \
+    case 2048: { constexpr int N = 2048; BODY; } break;  \
+    case 4096: { constexpr int N = 4096; BODY; } break;  \
+    default: break;                  \
+  }
+
+template <typename K>
+static hipError_t allow_lds(K kernel, size_t bytes) {
+  if (bytes <= 48 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)bytes);
+}
+
+static int launch_rows_r2c(const RegPlan& p, const void* src, int kind, long long plane_stride, float in_scale,
+                           cf* F, long long F_stride, int n, const cf* tw_x, hipStream_t st) {
+  IAP_FOR_N(p.Px, {
+    using Gm = FftGeom<N>;
+    size_t lds = (size_t)Gm::G * Gm::PADN * sizeof(cf);
+    IAP_HIP(allow_lds(rows_r2c_kernel<N>, lds));
+    hipLaunchKernelGGL(rows_r2c_kernel<N>, dim3(p.row_blocks, n), dim3(Gm::G * Gm::NT), lds, st, src, kind,
+                       plane_stride, p.X, p.oy, p.ox, in_scale, F, F_stride, p.Wp, tw_x);
+  });
+  IAP_LAUNCH_CHECK();
+  return IAP_OK;
+}
+
+static int launch_cols(const RegPlan& p, cf* F, long long F_stride, const cf* Gref, cf* R, long long R_stride, int n,
+                       const cf* tw_y, int mode, int normalize, hipStream_t st) {
+  float scale = 1.0f / ((float)p.Py * (float)p.Px);
+  IAP_FOR_N(p.Py, {
+    using Gm = FftGeom<N>;
+    size_t lds = (size_t)Gm::TC * Gm::CS * sizeof(cf);
+    IAP_HIP(allow_lds(cols_kernel<N>, lds));
+    hipLaunchKernelGGL(cols_kernel<N>, dim3(p.col_blocks, n), dim3(Gm::TC * Gm::NT), lds, st, F, F_stride, Gref, R,
+                       R_stride, p.Wp, tw_y, mode, normalize, scale);
+  });
+  IAP_LAUNCH_CHECK();
+  return IAP_OK;
+}
+
+static int launch_rows_c2r(const RegPlan& p, const cf* Q, long long Q_stride, int n, const cf* tw_x, float* pval,
+                           int* pidx, hipStream_t st) {
+  IAP_FOR_N(p.Px, {
+    using Gm = FftGeom<N>;
+    size_t lds = (size_t)Gm::G * Gm::PADN * sizeof(cf);
+    IAP_HIP(allow_lds(rows_c2r_argmax_kernel<N>, lds));
+    hipLaunchKernelGGL(rows_c2r_argmax_kernel<N>, dim3(p.row_blocks, n), dim3(Gm::G * Gm::NT), lds, st, Q, Q_stride,
+                       p.Wp, tw_x, pval, pidx);
+  });
+  IAP_LAUNCH_CHECK();
+  return IAP_OK;
+}
+
+static int reg_init_tables(const RegPlan& p, RegWs& w, hipStream_t st) {
+  hipLaunchKernelGGL(twiddle_kernel, dim3((p.Px + 255) / 256), dim3(256), 0, st, w.tw_x, p.Px);
+  hipLaunchKernelGGL(twiddle_kernel, dim3((p.Py + 255) / 256), dim3(256), 0, st, w.tw_y, p.Py);
+  IAP_LAUNCH_CHECK();
+  return IAP_OK;
+}
+
+// full 2-D spectrum of the reference plane into w.refspec
+static int reg_ref_spectrum(const RegPlan& p, RegWs& w, const void* ref, int kind, float in_scale, hipStream_t st) {
+  int rc = launch_rows_r2c(p, ref, kind, 0, in_scale, w.refspec, 0, 1, w.tw_x, st);
+  if (rc) return rc;
+  return launch_cols(p, w.refspec, 0, nullptr, nullptr, 0, 1, w.tw_y, 0, 0, st);
+}
+
+// shifts for n moving planes (n <= w.batch) against w.refspec
+static int reg_estimate_batch(const RegPlan& p, RegWs& w, const uint16_t* mov, long long mov_stride, int n, int flags,
+                              double* shifts, hipStream_t st) {
+  const long long fs = (long long)(align256(p.spec * 8) / 8);
+  const bool up = flags & IAP_REG_UPSAMPLE;
+  int rc = launch_rows_r2c(p, mov, 0, mov_stride, 1.0f, w.F, fs, n, w.tw_x, st);
+  if (rc) return rc;
+  rc = launch_cols(p, w.F, fs, w.refspec, up ? w.R : nullptr, fs, n, w.tw_y, 1, (flags & IAP_REG_NORMALIZE) ? 1 : 0,
+                   st);
+  if (rc) return rc;
+  rc = launch_rows_c2r(p, w.F, fs, n, w.tw_x, w.pval, w.pidx, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(coarse_finish_kernel, dim3(n), dim3(256), 0, st, (const float*)w.pval, (const int*)w.pidx,
+                     p.row_blocks, p.Py, p.Px, w.coarse, shifts, up ? 0 : 1);
+  if (up) {
+    int nch = p.ncg * p.nuc;
+    hipLaunchKernelGGL(upsample_partial_kernel, dim3(nch, n), dim3(256), 0, st, (const cf*)w.R, fs, p.Wp, p.Py, p.Px,
+                       p.ncg, (const int2*)w.coarse, w.upart);
+    hipLaunchKernelGGL(upsample_finish_kernel, dim3(n), dim3(256), 0, st, (const float*)w.upart, nch,
+                       (const int2*)w.coarse, shifts);
+  }
+  IAP_LAUNCH_CHECK();
+  return IAP_OK;
+}
+
+static int launch_mip(const uint16_t* in, long long in_stride, uint16_t* out, long long n, int Z, long long px,
+                      hipStream_t st) {
+  unsigned gx = (unsigned)((px / 8 + 255) / 256);
+  if (gx > 512) gx = 512;
+  if (gx == 0) gx = 1;
+  for (long long i0 = 0; i0 < n; i0 += 32768) {
+    long long nb = n - i0 < 32768 ? n - i0 : 32768;
+    hipLaunchKernelGGL(mip_kernel, dim3(gx, (unsigned)nb), dim3(256), 0, st, in + i0 * in_stride, in_stride,
+                       out + i0 * px, Z, px);
+  }
+  IAP_LAUNCH_CHECK();
+  return IAP_OK;
+}
+
+static int launch_apply(const uint16_t* in, uint16_t* out, long long n_frames, long long ppf, int Y, int X,
+                        const double* shifts, hipStream_t st) {
+  long long planes = n_frames * ppf;
+  dim3 grid((X + AP_TX - 1) / AP_TX, (Y + AP_TY - 1) / AP_TY, 1);
+  // blockIdx.z is limited to 65535: chunk by whole frames
+  long long fpc = 65535 / ppf;
+  if (fpc < 1) return IAP_E_UNSUPPORTED;
+  for (long long f0 = 0; f0 < n_frames; f0 += fpc) {
+    long long nf = n_frames - f0 < fpc ? n_frames - f0 : fpc;
+    grid.z = (unsigned)(nf * ppf);
+    hipLaunchKernelGGL(apply_shift_kernel, grid, dim3(256), 0, st, in + (size_t)f0 * ppf * Y * X,
+                       out + (size_t)f0 * ppf * Y * X, ppf, Y, X, shifts + 2 * f0);
+  }
+  (void)planes;
+  IAP_LAUNCH_CHECK();
+  return IAP_OK;
+}
+
+}  // namespace iap
+
+using namespace iap;
+
+extern "C" int iap_mip_u16(const uint16_t* in, int64_t in_stride, uint16_t* out, int64_t n, int Z, int Y, int X,
+                           void* stream) {
+  IAP_REQUIRE(in && out, IAP_E_ARG, "iap_mip_u16: null pointer");
+  IAP_REQUIRE(n > 0 && Z > 0 && Y > 0 && X > 0, IAP_E_ARG, "iap_mip_u16: non-positive size");
+  long long px = (long long)Y * X;
+  IAP_REQUIRE(in_stride >= (int64_t)Z * px, IAP_E_ARG, "iap_mip_u16: in_stride smaller than one item");
+  IAP_REQUIRE(aligned16(in) && aligned16(out) && (px % 8 == 0 || n == 1) && in_stride % 8 == 0, IAP_E_ALIGN,
+              "iap_mip_u16: pointers must be 16-byte aligned and Y*X, in_stride multiples of 8");
+  return launch_mip(in, in_stride, out, n, Z, px, as_stream(stream));
+}
+
+extern "C" size_t iap_reg_ws_bytes(int Y, int X, int Z, int batch) {
+  RegPlan p;
+  if (Y <= 0 || X <= 0 || Z <= 0 || !make_plan(Y, X, p)) return 0;
+  if (batch < 1) batch = 1;
+  return reg_fixed_bytes(p) + (size_t)batch * reg_frame_bytes(p, Z) + 512;
+}
+
+static int reg_check(const char* fn, int Y, int X, RegPlan& p) {
+  IAP_REQUIRE(Y > 0 && X > 0, IAP_E_ARG, "%s: non-positive plane size", fn);
+  IAP_REQUIRE(make_plan(Y, X, p), IAP_E_UNSUPPORTED, "%s: planes must be at least 64x64 (got %dx%d)", fn, Y, X);
+  return IAP_OK;
+}
+
+extern "C" int iap_reg_estimate_u16(const void* ref, int ref_kind, const uint16_t* mov, int64_t mov_stride, int64_t n,
+                                    int Y, int X, int flags, double* shifts_out, void* ws, size_t ws_bytes,
+                                    void* stream) {
+  IAP_REQUIRE(ref && mov && shifts_out && ws, IAP_E_ARG, "iap_reg_estimate_u16: null pointer");
+  IAP_REQUIRE(n > 0, IAP_E_ARG, "iap_reg_estimate_u16: n must be positive");
+  IAP_REQUIRE(ref_kind >= 0 && ref_kind <= 2, IAP_E_ARG, "iap_reg_estimate_u16: ref_kind must be 0, 1 or 2");
+  IAP_REQUIRE(mov_stride >= (int64_t)Y * X || n == 1, IAP_E_ARG, "iap_reg_estimate_u16: mov_stride too small");
+  RegPlan p;
+  int rc = reg_check("iap_reg_estimate_u16", Y, X, p);
+  if (rc) return rc;
+  RegWs w;
+  IAP_REQUIRE(carve(ws, ws_bytes, p, 1, w), IAP_E_WS, "iap_reg_estimate_u16: workspace of %zu bytes, need %zu",
+              ws_bytes, iap_reg_ws_bytes(Y, X, 1, 1));
+  hipStream_t st = as_stream(stream);
+  rc = reg_init_tables(p, w, st);
+  if (rc) return rc;
+  rc = reg_ref_spectrum(p, w, ref, ref_kind, 1.0f, st);
+  if (rc) return rc;
+  for (int64_t f0 = 0; f0 < n; f0 += w.batch) {
+    int nb = (int)(n - f0 < w.batch ? n - f0 : w.batch);
+    rc = reg_estimate_batch(p, w, mov + f0 * mov_stride, mov_stride, nb, flags, shifts_out + 2 * f0, st);
+    if (rc) return rc;
+  }
+  return IAP_OK;
+}
+
+extern "C" int iap_apply_shift_u16(const uint16_t* in, uint16_t* out, int64_t n_frames, int64_t planes_per_frame,
+                                   int Y, int X, const double* shifts, void* stream) {
+  IAP_REQUIRE(in && out && shifts, IAP_E_ARG, "iap_apply_shift_u16: null pointer");
+  IAP_REQUIRE(in != out, IAP_E_ARG, "iap_apply_shift_u16: in-place operation is not supported");
+  IAP_REQUIRE(n_frames > 0 && planes_per_frame > 0 && Y > 0 && X > 0, IAP_E_ARG,
+              "iap_apply_shift_u16: non-positive size");
+  IAP_REQUIRE(planes_per_frame <= 65535, IAP_E_UNSUPPORTED, "iap_apply_shift_u16: more than 65535 planes per frame");
+  return launch_apply(in, out, n_frames, planes_per_frame, Y, X, shifts, as_stream(stream));
+}
+
+extern "C" int iap_im_reg_u16(const uint16_t* in, uint16_t* out, int64_t T, int C, int Z, int Y, int X,
+                              int reg_channel, int ref_mode, int flags, double* shifts_out, void* ws, size_t ws_bytes,
+                              void* stream) {
+  IAP_REQUIRE(in && out && shifts_out && ws, IAP_E_ARG, "iap_im_reg_u16: null pointer");
+  IAP_REQUIRE(in != out, IAP_E_ARG, "iap_im_reg_u16: out must not alias in");
+  IAP_REQUIRE(T > 0 && C > 0 && Z > 0, IAP_E_ARG, "iap_im_reg_u16: non-positive size");
+  IAP_REQUIRE(reg_channel >= 0 && reg_channel < C, IAP_E_ARG, "iap_im_reg_u16: reg_channel %d not in 0..%d",
+              reg_channel, C - 1);
+  IAP_REQUIRE(ref_mode >= 0 && ref_mode <= 2, IAP_E_ARG,
+              "iap_im_reg_u16: ref_mode must be IAP_REF_FIRST, _MEAN or _PREVIOUS");
+  IAP_REQUIRE((int64_t)C * Z <= 65535 && T <= 65535, IAP_E_UNSUPPORTED, "iap_im_reg_u16: T and C*Z must be <= 65535");
+  RegPlan p;
+  int rc = reg_check("iap_im_reg_u16", Y, X, p);
+  if (rc) return rc;
+  const long long px = (long long)Y * X;
+  IAP_REQUIRE(Z == 1 || (px % 8 == 0 && aligned16(in) && aligned16(out)), IAP_E_ALIGN,
+              "iap_im_reg_u16: z-stacks need 16-byte aligned buffers and Y*X %% 8 == 0");
+  RegWs w;
+  IAP_REQUIRE(carve(ws, ws_bytes, p, Z, w), IAP_E_WS, "iap_im_reg_u16: workspace of %zu bytes, need %zu", ws_bytes,
+              iap_reg_ws_bytes(Y, X, Z, 1));
+  hipStream_t st = as_stream(stream);
+  rc = reg_init_tables(p, w, st);
+  if (rc) return rc;
+  const long long ppf = (long long)C * Z;
+  const long long frame_stride = ppf * px;
+  const long long chan_off = (long long)reg_channel * Z * px;
+
+  // moving planes of frames [f0, f0+nb): either straight from the stack (Z == 1) or z-MIPs
+  auto mov_planes = [&](const uint16_t* stack, long long f0, int nb, const uint16_t*& mp, long long& ms) -> int {
+    if (Z == 1) {
+      mp = stack + f0 * frame_stride + chan_off;
+      ms = frame_stride;
+      return IAP_OK;
+    }
+    int r = launch_mip(stack + f0 * frame_stride + chan_off, frame_stride, w.mip, nb, Z, px, st);
+    mp = w.mip;
+    ms = px;
+    return r;
+  };
+
+  if (ref_mode == IAP_REF_PREVIOUS) {
+    IAP_HIP(hipMemcpyAsync(out, in, (size_t)frame_stride * 2, hipMemcpyDeviceToDevice, st));
+    IAP_HIP(hipMemsetAsync(shifts_out, 0, 16, st));
+    for (long long f = 1; f < T; ++f) {
+      const uint16_t* refp;
+      if (Z == 1) {
+        refp = out + (f - 1) * frame_stride + chan_off;
+      } else {
+        rc = launch_mip(out + (f - 1) * frame_stride + chan_off, frame_stride, w.mip_ref, 1, Z, px, st);
+        if (rc) return rc;
+        refp = w.mip_ref;
+      }
+      rc = reg_ref_spectrum(p, w, refp, 0, 1.0f, st);
+      if (rc) return rc;
+      const uint16_t* mp;
+      long long ms;
+      rc = mov_planes(in, f, 1, mp, ms);
+      if (rc) return rc;
+      rc = reg_estimate_batch(p, w, mp, ms, 1, flags, shifts_out + 2 * f, st);
+      if (rc) return rc;
+      rc = launch_apply(in + f * frame_stride, out + f * frame_stride, 1, ppf, Y, X, shifts_out + 2 * f, st);
+      if (rc) return rc;
+    }
+    return IAP_OK;
+  }
+
+  if (ref_mode == IAP_REF_FIRST) {
+    const uint16_t* mp;
+    long long ms;
+    if (Z == 1) {
+      mp = in + chan_off;
+    } else {
+      rc = launch_mip(in + chan_off, frame_stride, w.mip_ref, 1, Z, px, st);
+      if (rc) return rc;
+      mp = w.mip_ref;
+    }
+    (void)ms;
+    rc = reg_ref_spectrum(p, w, mp, 0, 1.0f, st);
+    if (rc) return rc;
+  } else {  // mean over T of the (MIP) planes: exact u32 sum, scaled by 1/T on load
+    IAP_HIP(hipMemsetAsync(w.sum, 0, (size_t)px * 4, st));
+    unsigned gx = (unsigned)((px + 255) / 256);
+    if (gx > 4096) gx = 4096;
+    for (long long f0 = 0; f0 < T; f0 += w.batch) {
+      int nb = (int)(T - f0 < w.batch ? T - f0 : w.batch);
+      const uint16_t* mp;
+      long long ms;
+      rc = mov_planes(in, f0, nb, mp, ms);
+      if (rc) return rc;
+      hipLaunchKernelGGL(accum_planes_kernel, dim3(gx), dim3(256), 0, st, mp, ms, (long long)nb, px, w.sum);
+    }
+    IAP_LAUNCH_CHECK();
+    rc = reg_ref_spectrum(p, w, w.sum, 1, 1.0f / (float)T, st);
+    if (rc) return rc;
+  }
+  for (long long f0 = 0; f0 < T; f0 += w.batch) {
+    int nb = (int)(T - f0 < w.batch ? T - f0 : w.batch);
+    const uint16_t* mp;
+    long long ms;
+    rc = mov_planes(in, f0, nb, mp, ms);
+    if (rc) return rc;
+    rc = reg_estimate_batch(p, w, mp, ms, nb, flags, shifts_out + 2 * f0, st);
+    if (rc) return rc;
+  }
+  return launch_apply(in, out, T, ppf, Y, X, shifts_out, st);
+}

@@ -222,3 +222,92 @@ def gauss_blur(planes: torch.Tensor, ksize=(15, 15), sigma: float = 5.0) -> torc
     _lib.check(lib.iap_gauss_blur_u16(planes.data_ptr(), out.data_ptr(), n, y, x, int(ksize[0]), int(ksize[1]),
                                       float(sigma), _stream()), "iap_gauss_blur_u16")
     return out
+
+
+# ----------------------------------------------------------------------------- registration
+
+DEFAULT_REG_BATCH = 8
+
+
+def mip(stack: torch.Tensor) -> torch.Tensor:
+    """np.amax over z (utility.py:335,341): u16 (n, Z, Y, X) -> (n, Y, X)."""
+    _need_cuda(stack)
+    _u16(stack)
+    n, z, y, x = stack.shape
+    out = torch.empty((n, y, x), dtype=torch.uint16, device=stack.device)
+    lib = _lib.load()
+    _lib.check(lib.iap_mip_u16(stack.data_ptr(), z * y * x, out.data_ptr(), n, z, y, x, _stream()), "iap_mip_u16")
+    return out
+
+
+def _reg_flags(upsample: bool, normalize: bool) -> int:
+    return (REG_UPSAMPLE if upsample else 0) | (REG_NORMALIZE if normalize else 0)
+
+
+def estimate_shifts(ref: torch.Tensor, mov: torch.Tensor, upsample: bool = True, normalize: bool = False,
+                    batch: int = DEFAULT_REG_BATCH) -> torch.Tensor:
+    """(dy, dx) to apply to each moving plane so that it overlays ``ref`` (replaces
+    StackReg.register, utility.py:340).  ref: (Y, X) u16 / int32-sums / f32; mov: (n, Y, X) u16.
+    Returns a float64 (n, 2) device tensor."""
+    _need_cuda(ref, mov)
+    _u16(mov)
+    kind = {torch.uint16: 0, torch.int32: 1, torch.float32: 2}.get(ref.dtype)
+    if kind is None:
+        raise TypeError("ref must be uint16, int32 (sum of planes) or float32")
+    if mov.dim() == 2:
+        mov = mov[None]
+    n, y, x = mov.shape
+    if tuple(ref.shape) != (y, x):
+        raise ValueError("ref and mov plane shapes differ")
+    lib = _lib.load()
+    nb = lib.iap_reg_ws_bytes(y, x, 1, max(1, min(batch, n)))
+    if nb == 0:
+        raise ValueError(f"registration needs planes of at least 64x64, got {y}x{x}")
+    ws = _workspace(nb, mov.device)
+    shifts = torch.empty((n, 2), dtype=torch.float64, device=mov.device)
+    _lib.check(lib.iap_reg_estimate_u16(ref.data_ptr(), kind, mov.data_ptr(), y * x, n, y, x,
+                                        _reg_flags(upsample, normalize), shifts.data_ptr(), ws.data_ptr(), ws.numel(),
+                                        _stream()), "iap_reg_estimate_u16")
+    return shifts
+
+
+def apply_shifts(stack: torch.Tensor, shifts: torch.Tensor) -> torch.Tensor:
+    """StackReg.transform + clip + astype(uint16) (utility.py:351-355): stack u16 (T, ..., Y, X),
+    shifts f64 (T, 2); every plane of frame f is warped by shifts[f]."""
+    _need_cuda(stack, shifts)
+    _u16(stack)
+    if shifts.dtype != torch.float64 or shifts.shape != (stack.shape[0], 2):
+        raise ValueError("shifts must be float64 of shape (T, 2)")
+    t = stack.shape[0]
+    y, x = stack.shape[-2:]
+    ppf = stack.numel() // (t * y * x)
+    out = torch.empty_like(stack)
+    lib = _lib.load()
+    _lib.check(lib.iap_apply_shift_u16(stack.data_ptr(), out.data_ptr(), t, ppf, y, x, shifts.data_ptr(), _stream()),
+               "iap_apply_shift_u16")
+    return out
+
+
+def im_reg(stack: torch.Tensor, reg_channel: int = 0, reg_ref: str = "mean", upsample: bool = True,
+           normalize: bool = False, batch: int = DEFAULT_REG_BATCH, out: torch.Tensor | None = None):
+    """utility.py:274-430 (translation) on a resident stack u16 (T, C, Z, Y, X).
+    Returns (registered stack, shifts f64 (T, 2))."""
+    _need_cuda(stack)
+    _u16(stack)
+    if stack.dim() != 5:
+        raise ValueError("stack must be (T, C, Z, Y, X)")
+    if reg_ref not in REF_MODES:
+        raise ValueError(f"{reg_ref} is not valid. Please only put {list(REF_MODES)}")
+    t, c, z, y, x = stack.shape
+    lib = _lib.load()
+    nb = lib.iap_reg_ws_bytes(y, x, z, max(1, min(batch, t)))
+    if nb == 0:
+        raise ValueError(f"registration needs planes of at least 64x64, got {y}x{x}")
+    ws = _workspace(nb, stack.device)
+    if out is None:
+        out = torch.empty_like(stack)
+    shifts = torch.zeros((t, 2), dtype=torch.float64, device=stack.device)
+    _lib.check(lib.iap_im_reg_u16(stack.data_ptr(), out.data_ptr(), t, c, z, y, x, int(reg_channel),
+                                  REF_MODES[reg_ref], _reg_flags(upsample, normalize), shifts.data_ptr(),
+                                  ws.data_ptr(), ws.numel(), _stream()), "iap_im_reg_u16")
+    return out, shifts

@@ -196,8 +196,8 @@ def gauss_blur(img: np.ndarray, ksize=(15, 15), sigma: float = 5.0) -> np.ndarra
 # a4: translation estimate by FFT phase correlation
 # --------------------------------------------------------------------------------------
 
-COARSE_HALF = 7      # stage 1: offsets -0.7 .. +0.7 in steps of 0.1
-FINE_HALF = 10       # stage 2: offsets -0.10 .. +0.10 in steps of 0.01
+UP_HALF = 7          # sub-pixel grid: offsets -0.7 .. +0.7 in steps of UP_STEP
+UP_STEP = 0.1
 
 
 def fft_window(n: int) -> int:
@@ -213,19 +213,29 @@ def _crop_center(a: np.ndarray) -> np.ndarray:
     return a[oy:oy + py, ox:ox + px]
 
 
-def cross_power(ref: np.ndarray, mov: np.ndarray) -> np.ndarray:
-    """Normalised cross-power spectrum R = F conj(G) / |F conj(G)| (0 where |.| == 0)."""
+def cross_power(ref: np.ndarray, mov: np.ndarray, normalize: bool = False) -> np.ndarray:
+    """Cross-power spectrum P = F conj(G) with the DC bin zeroed (a constant offset carries no
+    shift information); normalize=True divides by |P| (phase correlation proper).
+
+    The default is the un-normalised form -- what skimage 0.18's phase_cross_correlation
+    computes (_phase_cross_correlation.py:204-207) -- because on photon-noise-limited frames
+    the whitened spectrum is dominated by noise bins: measured sub-pixel error 0.1-1 px with
+    normalisation versus ~1e-3 px without ('estimator choice')."""
     f = np.fft.fft2(_crop_center(np.asarray(ref, dtype=np.float64)))
     g = np.fft.fft2(_crop_center(np.asarray(mov, dtype=np.float64)))
     p = f * np.conj(g)
-    m = np.abs(p)
-    r = np.zeros_like(p)
-    np.divide(p, m, out=r, where=m > 0)
-    return r
+    if normalize:
+        m = np.abs(p)
+        r = np.zeros_like(p)
+        np.divide(p, m, out=r, where=m > 0)
+        p = r
+    p[0, 0] = 0
+    return p
 
 
 def _upsampled(r: np.ndarray, ys: np.ndarray, xs: np.ndarray) -> np.ndarray:
-    """Real part of sum_uv R[u,v] exp(2 pi i (u y/Ny + v x/Nx)) for fractional y, x."""
+    """Real part of sum_uv R[u,v] exp(2 pi i (u y/Ny + v x/Nx)) for fractional y, x
+    (matrix-multiply DFT, skimage _upsampled_dft)."""
     ny, nx = r.shape
     fu = np.fft.fftfreq(ny) * ny  # signed integer frequencies
     fv = np.fft.fftfreq(nx) * nx
@@ -236,23 +246,25 @@ def _upsampled(r: np.ndarray, ys: np.ndarray, xs: np.ndarray) -> np.ndarray:
 
 def _parabola(vm: float, v0: float, vp: float) -> float:
     den = vm - 2.0 * v0 + vp
-    if den >= 0:
+    if not den < 0:
         return 0.0
     d = 0.5 * (vm - vp) / den
     return float(min(0.5, max(-0.5, d)))
 
 
-def phase_shift(ref: np.ndarray, mov: np.ndarray, upsample: bool = True) -> tuple[float, float]:
+def phase_shift(ref: np.ndarray, mov: np.ndarray, upsample: bool = True, normalize: bool = False) -> tuple[float, float]:
     """(dy, dx) to apply to ``mov`` to register it onto ``ref``.
 
-    coarse : argmax (first in row-major order) of the real inverse FFT of R, wrapped to
+    coarse : argmax (first in row-major order) of the real inverse FFT of P, wrapped to
              the signed range (index > N/2 -> index - N), as skimage
              _phase_cross_correlation.py:204-220.
-    fine   : two-stage matrix-DFT upsampling (0.1 px grid over +-0.7, then 0.01 px grid
-             over +-0.10; the Guizar-Sicairos scheme of skimage :232-250, made
-             hierarchical), finished by a 1-D parabolic vertex per axis on the 0.01 grid.
+    fine   : matrix-DFT upsampling (skimage :232-250, Guizar-Sicairos) on a 0.1 px grid over
+             +-0.7 px around the coarse peak, finished by a 1-D parabolic vertex per axis.
+             (A 0.01 px grid, skimage's upsample_factor=100, cannot be resolved in float32:
+             neighbouring grid values of the broad correlation peak differ by < 1e-6
+             relative; the parabola reaches ~1e-3 px instead.)
     """
-    r = cross_power(ref, mov)
+    r = cross_power(ref, mov, normalize)
     ny, nx = r.shape
     c = np.fft.ifft2(r).real
     k = int(np.argmax(c))
@@ -262,19 +274,16 @@ def phase_shift(ref: np.ndarray, mov: np.ndarray, upsample: bool = True) -> tupl
     if not upsample:
         return float(sy), float(sx)
     cy, cx = float(sy), float(sx)
-    for half, step in ((COARSE_HALF, 0.1), (FINE_HALF, 0.01)):
-        offs = np.arange(-half, half + 1) * step
-        v = _upsampled(r, cy + offs, cx + offs)
-        k = int(np.argmax(v))
-        iy, ix = divmod(k, len(offs))
-        last = (iy, ix, v, offs, step)
-        cy, cx = cy + offs[iy], cx + offs[ix]
-    iy, ix, v, offs, step = last
+    offs = np.arange(-UP_HALF, UP_HALF + 1) * UP_STEP
+    v = _upsampled(r, cy + offs, cx + offs)
+    k = int(np.argmax(v))
     n = len(offs)
+    iy, ix = divmod(k, n)
+    cy, cx = cy + offs[iy], cx + offs[ix]
     if 0 < iy < n - 1:
-        cy += step * _parabola(v[iy - 1, ix], v[iy, ix], v[iy + 1, ix])
+        cy += UP_STEP * _parabola(v[iy - 1, ix], v[iy, ix], v[iy + 1, ix])
     if 0 < ix < n - 1:
-        cx += step * _parabola(v[iy, ix - 1], v[iy, ix], v[iy, ix + 1])
+        cx += UP_STEP * _parabola(v[iy, ix - 1], v[iy, ix], v[iy, ix + 1])
     return float(cy), float(cx)
 
 
@@ -369,7 +378,8 @@ def mip(vol: np.ndarray) -> np.ndarray:
     return np.amax(vol, axis=0)
 
 
-def im_reg_stack(stack: np.ndarray, reg_channel: int = 0, reg_ref: str = "mean", upsample: bool = True):
+def im_reg_stack(stack: np.ndarray, reg_channel: int = 0, reg_ref: str = "mean", upsample: bool = True,
+                 normalize: bool = False):
     """stack: u16 (T, C, Z, Y, X).  Returns (registered u16 stack, shifts (T, 2) f64).
 
     'first'   : ref = frame 0 (MIP over z)                       utility.py:332-355
@@ -394,7 +404,7 @@ def im_reg_stack(stack: np.ndarray, reg_channel: int = 0, reg_ref: str = "mean",
                 out[0] = stack[0]
                 continue
             ref = mips(out, f - 1).astype(np.float64)
-        dy, dx = phase_shift(ref, mips(stack, f), upsample=upsample)
+        dy, dx = phase_shift(ref, mips(stack, f), upsample=upsample, normalize=normalize)
         shifts[f] = (dy, dx)
         for ch in range(c):
             for zz in range(z):
