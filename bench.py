@@ -1,0 +1,287 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpx/s through background-subtract + register + per-label measure.
+
+One "step" = one pass of the whole hot path over one resident field of view:
+    iap_bg_smo_u16 (raw -> bg)  ->  iap_im_reg_u16 (bg -> registered)  ->
+    iap_measure_labels_u16 + iap_measure_finalize (registered + labels -> per-cell tables)
+Workload at N=1: BASELINE.json configs[1] -- one FOV, 4 channels, 2048x2048 uint16, 500 frames
+with sub-pixel drift ("c2").  With --gpus N every rank holds its own FOV (weak scaling, FOV
+sharding, no data-path collective); the per-cell row tables are gathered to every rank with one
+RCCL all_gather inside the timed step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` for the
+dominant kernel (HIP-event timing of every kernel launch of the timed steps, collected through
+iap_prof_*) and `cpu_baseline` (the numpy oracle = restated reference CPU path, timed on this
+host on a bounded sample of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from imageanalysis_pipeline_amd import _lib, ops, synth  # noqa: E402
+
+HBM_PEAK = 8.0e12  # B/s, MI355X datasheet (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
+
+WORKLOADS = {
+    # name: (T, C, Z, Y, X, n_cells)
+    "c1": (100, 2, 1, 512, 512, 60),        # BASELINE configs[0]
+    "c2": (500, 4, 1, 2048, 2048, 300),     # BASELINE configs[1]  (metric config)
+    "c2small": (64, 4, 1, 2048, 2048, 300),
+    "c3": (24, 2, 31, 2048, 2048, 300),     # configs[2] shape, T reduced (full T=200 is 104 GB + outputs)
+    "c5": (16, 1, 1, 2048, 2048, 0),        # configs[4]: 5041 labels per frame
+}
+
+# algorithmic (compulsory) HBM bytes per stack pixel, SURVEY.md section 8(d)
+def stage_bytes_per_px(c: int) -> dict:
+    return {"bg": 4.0, "estimate": 2.0 / c, "apply": 4.0, "measure": 2.0 + 2.0 / c}
+
+
+STAGE_OF_KERNEL = {
+    "smo_march_kernel": "bg", "smo_generic_kernel": "bg", "median_kernel": "bg", "sub_half_kernel": "bg",
+    "rows_r2c_kernel": "estimate", "cols_kernel": "estimate", "rows_c2r_argmax_kernel": "estimate",
+    "coarse_finish_kernel": "estimate", "upsample_partial_kernel": "estimate", "upsample_finish_kernel": "estimate",
+    "mip_kernel": "estimate", "accum_planes_kernel": "estimate",
+    "apply_shift_kernel": "apply", "measure_kernel": "measure", "measure_finalize_kernel": "measure",
+}
+
+
+def make_device_stack(t, c, z, y, x, n_cells, device, seed=0, subpixel=True):
+    """Synthetic stack generated on the device (torch is only the data generator here): Poisson(100)+400
+    background, Gaussian-blob cells, cumulative random-walk drift applied by Fourier shift before
+    quantisation.  Returns (stack u16 (T,C,Z,Y,X), labels u16 (T,Z,Y,X), drift)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    if n_cells > 0:
+        base = torch.from_numpy(synth.clean_frame(y, x, n_cells, seed)).to(device=device, dtype=torch.float32)
+        lab2d = synth.make_labels(y, x, n_cells, seed)
+    else:
+        base = torch.zeros((y, x), device=device)
+        lab2d = synth.make_dense_labels(y, x)
+    drift = synth.drift_walk(t, not subpixel, 1)
+    fb = torch.fft.rfft2(base)
+    fy = torch.fft.fftfreq(y, device=device)[:, None]
+    fx = torch.fft.rfftfreq(x, device=device)[None, :]
+    stack = torch.empty((t, c, z, y, x), dtype=torch.uint16, device=device)
+    zf = [1.0 - 0.6 * abs(k - (z - 1) / 2.0) / max(1.0, (z - 1) / 2.0) for k in range(z)] if z > 1 else [1.0]
+    lam = torch.full((y, x), 100.0, device=device)
+    for f in range(t):
+        ph = torch.exp(-2j * np.pi * (fy * float(drift[f, 0]) + fx * float(drift[f, 1])))
+        sh = torch.fft.irfft2(fb * ph, s=(y, x)).clamp_(min=0)
+        for ch in range(c):
+            for k in range(z):
+                v = torch.poisson(lam, generator=g) + 400.0 + sh * ((1 + 0.25 * ch) * zf[k])
+                stack[f, ch, k] = v.round_().clamp_(0, 65535).to(torch.int32).to(torch.uint16)
+    lab = ops.to_device_u16(lab2d, device)
+    labels = lab[None, None].expand(t, z, y, x).contiguous()
+    return stack, labels, drift
+
+
+class Path:
+    """The hot path on one resident FOV."""
+
+    def __init__(self, stack, labels, reg_ref="first", batch=8):
+        self.raw, self.labels = stack, labels
+        self.bg = torch.empty_like(stack)
+        self.reg = torch.empty_like(stack)
+        self.reg_ref, self.batch = reg_ref, batch
+        t, c, z, y, x = stack.shape
+        self.thr = ops.smo_threshold((y, x), device=stack.device)
+        self.n_labels = ops.max_label(labels) + 1
+
+    def step(self):
+        ops.bg_smo(self.raw, self.thr, out=self.bg)
+        _, self.shifts = ops.im_reg(self.bg, 0, self.reg_ref, upsample=True, batch=self.batch, out=self.reg)
+        acc = ops.measure_accumulate(self.reg, self.labels, self.n_labels)
+        self.tables = ops.measure_finalize(acc)
+        return self.tables
+
+
+def pack_rows(tables, rank):
+    """per-cell rows {fov, frame, label, area, mean[C], cz, cy, cx} of the labels present, as one f64 matrix"""
+    area, mean, cen, _ = tables
+    t, L = area.shape
+    idx = torch.nonzero(area > 0)
+    f, l = idx[:, 0], idx[:, 1]
+    rows = torch.cat([torch.full((idx.shape[0], 1), float(rank), dtype=torch.float64, device=area.device),
+                      f[:, None].double(), l[:, None].double(), area[f, l][:, None].double(), mean[f, l], cen[f, l]], 1)
+    return rows
+
+
+def gather_rows(rows, world):
+    import torch.distributed as dist
+    n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    nmax = int(max(int(c.item()) for c in counts))
+    pad = torch.zeros((nmax, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+    pad[: rows.shape[0]] = rows
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    return torch.cat([b[: int(c.item())] for b, c in zip(bufs, counts)], 0)
+
+
+def collect_kernel_times():
+    import ctypes
+    lib = _lib.load()
+    out = {}
+    for k in range(lib.iap_prof_kernel_count()):
+        ms = ctypes.c_double()
+        n = ctypes.c_int64()
+        _lib.check(lib.iap_prof_collect(k, ctypes.byref(ms), ctypes.byref(n)), "iap_prof_collect")
+        if n.value:
+            out[lib.iap_prof_kernel_name(k).decode()] = (ms.value, n.value)
+    return out
+
+
+def cpu_baseline(y, x, c, n_cells, budget_frames=2):
+    """The oracle (numpy restatement of the reference CPU path) on a bounded sample of the workload:
+    `budget_frames` frames x C channels of the same plane size, same stages."""
+    from oracle import ref_path as O
+    st, _ = synth.make_stack(budget_frames, c, 1, y, x, n_cells=n_cells, integer_drift=False)
+    lab = synth.make_labels(y, x, n_cells)[None, None].repeat(budget_frames, 0) if n_cells else \
+        synth.make_dense_labels(y, x)[None, None].repeat(budget_frames, 0)
+    thr = 0.05
+    t0 = time.perf_counter()
+    O.run_path(st, lab, thr, reg_ref="first")
+    dt = time.perf_counter() - t0
+    px = st.size
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    return {"value": px / dt / 1e6, "unit": "Mpx/s", "cores": 1, "kind": "port",
+            "sample": f"{budget_frames} frames x {c} ch x {y}x{x} of the same synthetic workload, numpy oracle "
+                      f"(single process; numpy/pocketfft threads: default; host exposes {cores} cores), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--frames", type=int, default=0, help="override T")
+    ap.add_argument("--reg-ref", default="first", choices=["first", "mean", "previous"])
+    ap.add_argument("--batch", type=int, default=8, help="frames per registration launch group")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stage-report", action="store_true", help="also print a per-kernel table to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP library is the only implementation)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    t, c, z, y, x, n_cells = WORKLOADS[args.workload]
+    if args.frames:
+        t = args.frames
+    stack, labels, _ = make_device_stack(t, c, z, y, x, n_cells, dev, seed=rank)
+    path = Path(stack, labels, args.reg_ref, args.batch)
+    lib = _lib.load()
+
+    def one_step():
+        tables = path.step()
+        if world > 1:
+            return gather_rows(pack_rows(tables, rank), world)
+        return tables
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timing = not args.no_kernel_timing
+    if timing:
+        lib.iap_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ktimes = collect_kernel_times() if timing else {}
+    lib.iap_prof_enable(0)
+
+    px_step = t * c * z * y * x
+    value = px_step * world * args.steps / dt / 1e6
+    bpp = stage_bytes_per_px(c)
+    total_bpp = sum(bpp.values())
+
+    roof = None
+    stages = {}
+    if ktimes:
+        for name, (ms, n) in ktimes.items():
+            s = STAGE_OF_KERNEL.get(name)
+            if s:
+                stages.setdefault(s, 0.0)
+                stages[s] += ms
+        dom = max(ktimes.items(), key=lambda kv: kv[1][0])
+        dname, (dms, dn) = dom
+        dstage = STAGE_OF_KERNEL.get(dname, "bg")
+        # algorithmic bytes of the dominant kernel's stage, per launch of that kernel
+        alg_bytes_launch = bpp[dstage] * px_step * args.steps / dn
+        avg_s = dms / dn / 1e3
+        achieved = alg_bytes_launch / avg_s
+        roof = {"bound": "hbm", "kernel": dname, "stage": dstage, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                "launches": dn, "avg_launch_ms": dms / dn,
+                "algorithmic_bytes_per_launch": alg_bytes_launch,
+                "note": "achieved = stage algorithmic bytes (SURVEY 8d: %.3g B/px x stack px) / launches / mean launch "
+                        "duration of the stage's dominant kernel (HIP events)" % bpp[dstage]}
+        prof = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(prof):
+            try:
+                roof["traffic"] = json.load(open(prof)).get(dname)
+            except Exception:
+                pass
+        if args.stage_report and rank == 0:
+            for name, (ms, n) in sorted(ktimes.items(), key=lambda kv: -kv[1][0]):
+                print(f"  {name:28s} {ms / args.steps:9.3f} ms/step  {n // args.steps:6d} launches/step", file=sys.stderr)
+
+    if rank == 0:
+        out = {
+            "metric": "Mpx/s through bg-sub+registration+mask measure",
+            "value": value, "unit": "Mpx/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: one FOV per GPU, T={t} C={c} Z={z} {y}x{x} uint16, sub-pixel drift, "
+                                   f"{n_cells or 5041} labels/frame, reg_ref={args.reg_ref}",
+                       "stages": "bg_smo + im_reg(estimate+apply) + measure_labels", "parallelism": f"fov-shard x{world}"},
+            "hbm_frac_end_to_end": value * 1e6 / world * total_bpp / HBM_PEAK,
+            "algorithmic_bytes_per_px": total_bpp,
+        }
+        if stages:
+            out["stage_ms_per_step"] = {k: v / args.steps for k, v in stages.items()}
+            out["stage_hbm_frac"] = {k: bpp[k] * px_step / (v / args.steps / 1e3) / HBM_PEAK for k, v in stages.items()}
+        if roof:
+            out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(y, x, c, n_cells or 0)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

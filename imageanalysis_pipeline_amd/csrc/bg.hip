@@ -575,12 +575,12 @@ static int launch_smo(const T* src, const uint16_t* orig, float* smo_out, unsign
   if (smo_fast_ok(Y, X, size)) {
     SmoGeom g = smo_geom(Y, X, pick_band(Y, n));
     long long blocks = (long long)n * g.tasks_per_plane / SMO_WAVES;
-    hipLaunchKernelGGL((smo_march_kernel<T, MODE>), dim3((unsigned)blocks), dim3(SMO_WAVES * 64), 0, st, src,
-                       orig, smo_out, hist, g, thr2, inv_area);
+    { ProfScope ps_(K_SMO_MARCH, st); hipLaunchKernelGGL((smo_march_kernel<T, MODE>), dim3((unsigned)blocks), dim3(SMO_WAVES * 64), 0, st, src,
+                       orig, smo_out, hist, g, thr2, inv_area); }
   } else {
     unsigned bx = (unsigned)(((long long)Y * X + 255) / 256);
-    hipLaunchKernelGGL((smo_generic_kernel<T, MODE>), dim3(bx, (unsigned)n), dim3(256), 0, st, src, orig,
-                       smo_out, hist, Y, X, size, thr2, inv_area);
+    { ProfScope ps_(K_SMO_GENERIC, st); hipLaunchKernelGGL((smo_generic_kernel<T, MODE>), dim3(bx, (unsigned)n), dim3(256), 0, st, src, orig,
+                       smo_out, hist, Y, X, size, thr2, inv_area); }
   }
   IAP_LAUNCH_CHECK();
   return IAP_OK;
@@ -591,10 +591,10 @@ static int launch_gauss_reflect(const T* in, float* tmp, float* out, int64_t n, 
                                 hipStream_t st) {
   int radius = (int)(4.0f * sigma + 0.5f);
   unsigned bx = (unsigned)(((long long)Y * X + 255) / 256);
-  hipLaunchKernelGGL((gauss_reflect_kernel<T>), dim3(bx, (unsigned)n), dim3(256), 0, st, in, tmp, Y, X, 0,
-                     radius, sigma);
-  hipLaunchKernelGGL((gauss_reflect_kernel<float>), dim3(bx, (unsigned)n), dim3(256), 0, st,
-                     (const float*)tmp, out, Y, X, 1, radius, sigma);
+  { ProfScope ps_(K_GAUSS, st); hipLaunchKernelGGL((gauss_reflect_kernel<T>), dim3(bx, (unsigned)n), dim3(256), 0, st, in, tmp, Y, X, 0,
+                     radius, sigma); }
+  { ProfScope ps_(K_GAUSS, st); hipLaunchKernelGGL((gauss_reflect_kernel<float>), dim3(bx, (unsigned)n), dim3(256), 0, st,
+                     (const float*)tmp, out, Y, X, 1, radius, sigma); }
   IAP_LAUNCH_CHECK();
   return IAP_OK;
 }
@@ -685,13 +685,13 @@ extern "C" int iap_bg_smo_u16(const uint16_t* in, uint16_t* out, int64_t n, int 
       rc = launch_smo<uint16_t, SMO_MODE_HIST>(bin, bin, nullptr, hist, nb, Y, X, size, threshold, st);
     }
     if (rc) return rc;
-    hipLaunchKernelGGL(median_kernel, dim3((unsigned)nb), dim3(256), 0, st, hist, med2, nbg,
-                       med2_out ? med2_out + p0 : nullptr, nbg_out ? nbg_out + p0 : nullptr);
+    { ProfScope ps_(K_MEDIAN, st); hipLaunchKernelGGL(median_kernel, dim3((unsigned)nb), dim3(256), 0, st, hist, med2, nbg,
+                       med2_out ? med2_out + p0 : nullptr, nbg_out ? nbg_out + p0 : nullptr); }
     unsigned gx = (unsigned)((px / 8 + 255) / 256);
     if (gx > 256) gx = 256;
     if (gx == 0) gx = 1;
-    hipLaunchKernelGGL(sub_half_kernel, dim3(gx, (unsigned)nb), dim3(256), 0, st, bin, bout, (long long)px,
-                       (const int*)med2);
+    { ProfScope ps_(K_SUB, st); hipLaunchKernelGGL(sub_half_kernel, dim3(gx, (unsigned)nb), dim3(256), 0, st, bin, bout, (long long)px,
+                       (const int*)med2); }
     IAP_LAUNCH_CHECK();
   }
   return IAP_OK;
@@ -713,15 +713,15 @@ extern "C" int iap_bg_const_u16(const uint16_t* in, uint16_t* out, int64_t n, in
   long long n_roi = (long long)(r1 - r0 + 1) * (c1 - c0 + 1);
   unsigned gx = (unsigned)((n_roi + 255) / 256);
   if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(roi_sum_kernel, dim3(gx, (unsigned)n), dim3(256), 0, st, in, (long long)Y * X, X, r0, c0, r1,
-                     c1, sums);
-  hipLaunchKernelGGL(roi_bg_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
-                     (const unsigned long long*)sums, n_roi, (long long)n, bg2, bg_out);
+  { ProfScope ps_(K_ROI, st); hipLaunchKernelGGL(roi_sum_kernel, dim3(gx, (unsigned)n), dim3(256), 0, st, in, (long long)Y * X, X, r0, c0, r1,
+                     c1, sums); }
+  { ProfScope ps_(K_ROI, st); hipLaunchKernelGGL(roi_bg_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                     (const unsigned long long*)sums, n_roi, (long long)n, bg2, bg_out); }
   long long px = (long long)Y * X;
   unsigned sx = (unsigned)((px / 8 + 255) / 256);
   if (sx > 256) sx = 256;
   if (sx == 0) sx = 1;
-  hipLaunchKernelGGL(sub_half_kernel, dim3(sx, (unsigned)n), dim3(256), 0, st, in, out, px, (const int*)bg2);
+  { ProfScope ps_(K_SUB, st); hipLaunchKernelGGL(sub_half_kernel, dim3(sx, (unsigned)n), dim3(256), 0, st, in, out, px, (const int*)bg2); }
   IAP_LAUNCH_CHECK();
   return IAP_OK;
 }
@@ -753,7 +753,7 @@ extern "C" int iap_gauss_blur_u16(const uint16_t* in, uint16_t* out, int64_t n, 
   int rx = (kx - 1) / 2, ry = (ky - 1) / 2;
   size_t lds = ((size_t)(GB_TY + 2 * ry) * (GB_TX + 2 * rx) + (size_t)(GB_TY + 2 * ry) * GB_TX + rx + ry + 2) * 4;
   dim3 grid((X + GB_TX - 1) / GB_TX, (Y + GB_TY - 1) / GB_TY, (unsigned)n);
-  hipLaunchKernelGGL(gauss_blur_kernel, grid, dim3(256), lds, st, in, out, Y, X, rx, ry, h);
+  { ProfScope ps_(K_GAUSS, st); hipLaunchKernelGGL(gauss_blur_kernel, grid, dim3(256), lds, st, in, out, Y, X, rx, ry, h); }
   IAP_LAUNCH_CHECK();
   return IAP_OK;
 }

@@ -41,6 +41,24 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
     }                                                                                   \
   } while (0)
 
+// Optional per-kernel timing with HIP events on the launch stream (iap_prof_* in iap.h).
+enum KernelId {
+  K_SMO_MARCH = 0, K_SMO_GENERIC, K_MEDIAN, K_SUB, K_ROWS_R2C, K_COLS, K_ROWS_C2R, K_COARSE, K_UPSAMPLE,
+  K_UPFINISH, K_APPLY, K_MEASURE, K_MEASURE_FIN, K_MIP, K_ACCUM, K_GAUSS, K_ROI, K_OTHER, K_COUNT
+};
+extern bool g_prof_on;
+void prof_mark(int kid, hipStream_t st, bool start);
+struct ProfScope {
+  int kid;
+  hipStream_t st;
+  ProfScope(int k, hipStream_t s) : kid(k), st(s) {
+    if (g_prof_on) prof_mark(kid, st, true);
+  }
+  ~ProfScope() {
+    if (g_prof_on) prof_mark(kid, st, false);
+  }
+};
+
 // 8 x u16 = one 16-byte lane access (guide G13: always vectorise 16-bit streams).
 struct alignas(16) u16x8 {
   uint16_t v[8];

@@ -225,13 +225,13 @@ static int launch_measure(const uint16_t* img, const uint16_t* labels, int64_t T
   if (zyx % 8 == 0) {
     unsigned chunk = MEAS_THREADS * MEAS_ITERS * 8;
     dim3 grid((zyx + chunk - 1) / chunk, (unsigned)T);
-    hipLaunchKernelGGL((measure_kernel<NC, COORDS, 8>), grid, dim3(MEAS_THREADS), 0, st, img, labels, zyx, C,
-                       c0, Y, X, L, a);
+    { ProfScope ps_(K_MEASURE, st); hipLaunchKernelGGL((measure_kernel<NC, COORDS, 8>), grid, dim3(MEAS_THREADS), 0, st, img, labels, zyx, C,
+                       c0, Y, X, L, a); }
   } else {
     unsigned chunk = MEAS_THREADS * MEAS_ITERS;
     dim3 grid((zyx + chunk - 1) / chunk, (unsigned)T);
-    hipLaunchKernelGGL((measure_kernel<NC, COORDS, 1>), grid, dim3(MEAS_THREADS), 0, st, img, labels, zyx, C,
-                       c0, Y, X, L, a);
+    { ProfScope ps_(K_MEASURE, st); hipLaunchKernelGGL((measure_kernel<NC, COORDS, 1>), grid, dim3(MEAS_THREADS), 0, st, img, labels, zyx, C,
+                       c0, Y, X, L, a); }
   }
   IAP_LAUNCH_CHECK();
   return IAP_OK;
@@ -287,9 +287,9 @@ extern "C" int iap_measure_finalize(const uint64_t* acc, int64_t T, int L, int C
   IAP_REQUIRE(T > 0 && L > 0 && C > 0, IAP_E_ARG, "iap_measure_finalize: non-positive size");
   long long rows = (long long)T * L;
   unsigned blocks = (unsigned)((rows + 255) / 256);
-  hipLaunchKernelGGL(measure_finalize_kernel, dim3(blocks), dim3(256), 0, as_stream(stream),
+  { ProfScope ps_(K_MEASURE_FIN, as_stream(stream)); hipLaunchKernelGGL(measure_finalize_kernel, dim3(blocks), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const unsigned long long*>(acc), rows, C,
-                     reinterpret_cast<long long*>(area), mean, centroid, reinterpret_cast<long long*>(centroid_rne));
+                     reinterpret_cast<long long*>(area), mean, centroid, reinterpret_cast<long long*>(centroid_rne)); }
   IAP_LAUNCH_CHECK();
   return IAP_OK;
 }
@@ -304,7 +304,7 @@ extern "C" int iap_max_u16(const uint16_t* labels, int64_t n, uint32_t* out, voi
   unsigned blocks = (unsigned)((nv + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   if (blocks == 0) blocks = 1;
-  hipLaunchKernelGGL(max_u16_kernel, dim3(blocks), dim3(256), 0, st, labels, (long long)n, out);
+  { ProfScope ps_(K_OTHER, st); hipLaunchKernelGGL(max_u16_kernel, dim3(blocks), dim3(256), 0, st, labels, (long long)n, out); }
   IAP_LAUNCH_CHECK();
   return IAP_OK;
 }

@@ -758,8 +758,8 @@ static int launch_rows_r2c(const RegPlan& p, const void* src, int kind, long lon
     using Gm = FftGeom<N>;
     size_t lds = (size_t)Gm::G * Gm::PADN * sizeof(cf);
     IAP_HIP(allow_lds(rows_r2c_kernel<N>, lds));
-    hipLaunchKernelGGL(rows_r2c_kernel<N>, dim3(p.row_blocks, n), dim3(Gm::G * Gm::NT), lds, st, src, kind,
-                       plane_stride, p.X, p.oy, p.ox, in_scale, F, F_stride, p.Wp, tw_x);
+    { ProfScope ps_(K_ROWS_R2C, st); hipLaunchKernelGGL(rows_r2c_kernel<N>, dim3(p.row_blocks, n), dim3(Gm::G * Gm::NT), lds, st, src, kind,
+                       plane_stride, p.X, p.oy, p.ox, in_scale, F, F_stride, p.Wp, tw_x); }
   });
   IAP_LAUNCH_CHECK();
   return IAP_OK;
@@ -772,8 +772,8 @@ static int launch_cols(const RegPlan& p, cf* F, long long F_stride, const cf* Gr
     using Gm = FftGeom<N>;
     size_t lds = (size_t)Gm::TC * Gm::CS * sizeof(cf);
     IAP_HIP(allow_lds(cols_kernel<N>, lds));
-    hipLaunchKernelGGL(cols_kernel<N>, dim3(p.col_blocks, n), dim3(Gm::TC * Gm::NT), lds, st, F, F_stride, Gref, R,
-                       R_stride, p.Wp, tw_y, mode, normalize, scale);
+    { ProfScope ps_(K_COLS, st); hipLaunchKernelGGL(cols_kernel<N>, dim3(p.col_blocks, n), dim3(Gm::TC * Gm::NT), lds, st, F, F_stride, Gref, R,
+                       R_stride, p.Wp, tw_y, mode, normalize, scale); }
   });
   IAP_LAUNCH_CHECK();
   return IAP_OK;
@@ -785,16 +785,16 @@ static int launch_rows_c2r(const RegPlan& p, const cf* Q, long long Q_stride, in
     using Gm = FftGeom<N>;
     size_t lds = (size_t)Gm::G * Gm::PADN * sizeof(cf);
     IAP_HIP(allow_lds(rows_c2r_argmax_kernel<N>, lds));
-    hipLaunchKernelGGL(rows_c2r_argmax_kernel<N>, dim3(p.row_blocks, n), dim3(Gm::G * Gm::NT), lds, st, Q, Q_stride,
-                       p.Wp, tw_x, pval, pidx);
+    { ProfScope ps_(K_ROWS_C2R, st); hipLaunchKernelGGL(rows_c2r_argmax_kernel<N>, dim3(p.row_blocks, n), dim3(Gm::G * Gm::NT), lds, st, Q, Q_stride,
+                       p.Wp, tw_x, pval, pidx); }
   });
   IAP_LAUNCH_CHECK();
   return IAP_OK;
 }
 
 static int reg_init_tables(const RegPlan& p, RegWs& w, hipStream_t st) {
-  hipLaunchKernelGGL(twiddle_kernel, dim3((p.Px + 255) / 256), dim3(256), 0, st, w.tw_x, p.Px);
-  hipLaunchKernelGGL(twiddle_kernel, dim3((p.Py + 255) / 256), dim3(256), 0, st, w.tw_y, p.Py);
+  { ProfScope ps_(K_OTHER, st); hipLaunchKernelGGL(twiddle_kernel, dim3((p.Px + 255) / 256), dim3(256), 0, st, w.tw_x, p.Px); }
+  { ProfScope ps_(K_OTHER, st); hipLaunchKernelGGL(twiddle_kernel, dim3((p.Py + 255) / 256), dim3(256), 0, st, w.tw_y, p.Py); }
   IAP_LAUNCH_CHECK();
   return IAP_OK;
 }
@@ -818,14 +818,14 @@ static int reg_estimate_batch(const RegPlan& p, RegWs& w, const uint16_t* mov, l
   if (rc) return rc;
   rc = launch_rows_c2r(p, w.F, fs, n, w.tw_x, w.pval, w.pidx, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(coarse_finish_kernel, dim3(n), dim3(256), 0, st, (const float*)w.pval, (const int*)w.pidx,
-                     p.row_blocks, p.Py, p.Px, w.coarse, shifts, up ? 0 : 1);
+  { ProfScope ps_(K_COARSE, st); hipLaunchKernelGGL(coarse_finish_kernel, dim3(n), dim3(256), 0, st, (const float*)w.pval, (const int*)w.pidx,
+                     p.row_blocks, p.Py, p.Px, w.coarse, shifts, up ? 0 : 1); }
   if (up) {
     int nch = p.ncg * p.nuc;
-    hipLaunchKernelGGL(upsample_partial_kernel, dim3(nch, n), dim3(256), 0, st, (const cf*)w.R, fs, p.Wp, p.Py, p.Px,
-                       p.ncg, (const int2*)w.coarse, w.upart);
-    hipLaunchKernelGGL(upsample_finish_kernel, dim3(n), dim3(256), 0, st, (const float*)w.upart, nch,
-                       (const int2*)w.coarse, shifts);
+    { ProfScope ps_(K_UPSAMPLE, st); hipLaunchKernelGGL(upsample_partial_kernel, dim3(nch, n), dim3(256), 0, st, (const cf*)w.R, fs, p.Wp, p.Py, p.Px,
+                       p.ncg, (const int2*)w.coarse, w.upart); }
+    { ProfScope ps_(K_UPFINISH, st); hipLaunchKernelGGL(upsample_finish_kernel, dim3(n), dim3(256), 0, st, (const float*)w.upart, nch,
+                       (const int2*)w.coarse, shifts); }
   }
   IAP_LAUNCH_CHECK();
   return IAP_OK;
@@ -838,8 +838,8 @@ static int launch_mip(const uint16_t* in, long long in_stride, uint16_t* out, lo
   if (gx == 0) gx = 1;
   for (long long i0 = 0; i0 < n; i0 += 32768) {
     long long nb = n - i0 < 32768 ? n - i0 : 32768;
-    hipLaunchKernelGGL(mip_kernel, dim3(gx, (unsigned)nb), dim3(256), 0, st, in + i0 * in_stride, in_stride,
-                       out + i0 * px, Z, px);
+    { ProfScope ps_(K_MIP, st); hipLaunchKernelGGL(mip_kernel, dim3(gx, (unsigned)nb), dim3(256), 0, st, in + i0 * in_stride, in_stride,
+                       out + i0 * px, Z, px); }
   }
   IAP_LAUNCH_CHECK();
   return IAP_OK;
@@ -855,8 +855,8 @@ static int launch_apply(const uint16_t* in, uint16_t* out, long long n_frames, l
   for (long long f0 = 0; f0 < n_frames; f0 += fpc) {
     long long nf = n_frames - f0 < fpc ? n_frames - f0 : fpc;
     grid.z = (unsigned)(nf * ppf);
-    hipLaunchKernelGGL(apply_shift_kernel, grid, dim3(256), 0, st, in + (size_t)f0 * ppf * Y * X,
-                       out + (size_t)f0 * ppf * Y * X, ppf, Y, X, shifts + 2 * f0);
+    { ProfScope ps_(K_APPLY, st); hipLaunchKernelGGL(apply_shift_kernel, grid, dim3(256), 0, st, in + (size_t)f0 * ppf * Y * X,
+                       out + (size_t)f0 * ppf * Y * X, ppf, Y, X, shifts + 2 * f0); }
   }
   (void)planes;
   IAP_LAUNCH_CHECK();
@@ -1016,7 +1016,7 @@ extern "C" int iap_im_reg_u16(const uint16_t* in, uint16_t* out, int64_t T, int 
       long long ms;
       rc = mov_planes(in, f0, nb, mp, ms);
       if (rc) return rc;
-      hipLaunchKernelGGL(accum_planes_kernel, dim3(gx), dim3(256), 0, st, mp, ms, (long long)nb, px, w.sum);
+      { ProfScope ps_(K_ACCUM, st); hipLaunchKernelGGL(accum_planes_kernel, dim3(gx), dim3(256), 0, st, mp, ms, (long long)nb, px, w.sum); }
     }
     IAP_LAUNCH_CHECK();
     rc = reg_ref_spectrum(p, w, w.sum, 1, 1.0f / (float)T, st);

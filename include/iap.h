@@ -132,6 +132,17 @@ int iap_measure_finalize(const uint64_t* acc, int64_t T, int L, int C,
 /* Max label value of a u16 label stack of n elements -> device u32 (zeroed by the call). */
 int iap_max_u16(const uint16_t* labels, int64_t n, uint32_t* out, void* stream);
 
+/* ------------------------------------------------------------------ instrumentation ---- */
+
+/* Optional per-kernel timing with HIP events recorded on the launch stream (no counterpart in
+ * the reference; used by bench.py for the roofline line).  iap_prof_enable(1) clears and starts
+ * recording, iap_prof_enable(0) stops; iap_prof_collect synchronises the recorded events and
+ * returns the summed duration and launch count of one kernel id (0 .. iap_prof_kernel_count()-1). */
+void iap_prof_enable(int on);
+int iap_prof_kernel_count(void);
+const char* iap_prof_kernel_name(int kernel_id);
+int iap_prof_collect(int kernel_id, double* total_ms, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

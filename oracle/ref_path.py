@@ -473,6 +473,11 @@ def measure_labels(img: np.ndarray, labels: np.ndarray):
 
 def run_path(stack: np.ndarray, labels: np.ndarray, threshold: float, reg_ref: str = "first",
              sigma: float = 0.0, size: int = 7):
+    return run_path_opts(stack, labels, threshold, reg_ref, sigma, size, True)
+
+
+def run_path_opts(stack: np.ndarray, labels: np.ndarray, threshold: float, reg_ref: str = "first",
+                  sigma: float = 0.0, size: int = 7, upsample: bool = True):
     """stack (T,C,Z,Y,X) u16, labels (T,Z,Y,X) u16 -> (registered stack, shifts, tables)."""
     t, c, z, y, x = stack.shape
     bg = np.empty_like(stack)
@@ -480,7 +485,7 @@ def run_path(stack: np.ndarray, labels: np.ndarray, threshold: float, reg_ref: s
         for ch in range(c):
             for zz in range(z):
                 bg[f, ch, zz] = bg_smo(stack[f, ch, zz], threshold, sigma, size)[0]
-    reg, shifts = im_reg_stack(bg, 0, reg_ref)
+    reg, shifts = im_reg_stack(bg, 0, reg_ref, upsample=upsample)
     tables = []
     for f in range(t):
         if z == 1:
