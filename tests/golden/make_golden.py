@@ -1,0 +1,86 @@
+"""Generates tests/golden/*.npz: inputs + expected outputs computed by THIRD-PARTY libraries
+(scikit-image 0.18.3, scipy) -- not by the reference (its numeric dependencies smo / pystackreg /
+cv2 are absent from the image) and not by the oracle under test.
+
+Run with the conda interpreter that has scikit-image:
+    /opt/conda/bin/python3.9 tests/golden/make_golden.py
+The fixtures pin oracle/ref_path.py in tests/test_oracle_golden.py.
+"""
+import os
+import sys
+
+import numpy as np
+import scipy.ndimage as ndi
+from skimage.measure import regionprops
+from skimage.registration import phase_cross_correlation
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from imageanalysis_pipeline_amd import synth  # noqa: E402  (numpy only)
+
+
+def golden_regionprops():
+    rng = np.random.default_rng(0)
+    y, x = 72, 96
+    lab = synth.make_labels(y, x, 9, seed=1).astype(np.int32)
+    img = rng.integers(0, 65536, size=(2, y, x)).astype(np.uint16)
+    ids, area, cen, mean = [], [], [], []
+    for rp in regionprops(lab, intensity_image=np.moveaxis(img, 0, -1)):
+        ids.append(rp.label)
+        area.append(rp.area)
+        cen.append(rp.centroid)
+        mean.append([float(np.mean(img[c][lab == rp.label])) for c in range(2)])
+    np.savez_compressed(os.path.join(HERE, "regionprops.npz"), labels=lab.astype(np.uint16), img=img,
+                        ids=np.array(ids), area=np.array(area), centroid=np.array(cen), mean=np.array(mean))
+
+
+def golden_shift():
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 60000, size=(40, 56)).astype(np.uint16)
+    shifts = np.array([[0.3, -1.7], [-2.5, 0.25], [3.0, -2.0], [0.0, 0.5], [10.2, 0.0]])
+    outs = np.stack([ndi.shift(a.astype(np.float64), s, order=3, mode="constant", cval=0.0) for s in shifts])
+    np.savez_compressed(os.path.join(HERE, "ndimage_shift.npz"), img=a, shifts=shifts, out=outs)
+
+
+def golden_smo():
+    rng = np.random.default_rng(2)
+    img = (rng.poisson(100, size=(48, 64)) + 400).astype(np.uint16)
+    img[10:20, 30:50] += 900
+
+    def smo_scipy(a, sigma, size):
+        a = a.astype(float)
+        if sigma > 0:
+            a = ndi.gaussian_filter(a, sigma)
+        g = np.gradient(a)
+        n = np.sqrt(g[0] ** 2 + g[1] ** 2)
+        ny = np.divide(g[0], n, out=np.zeros_like(a), where=n > 0)
+        nx = np.divide(g[1], n, out=np.zeros_like(a), where=n > 0)
+        return np.sqrt(ndi.uniform_filter(ny, size) ** 2 + ndi.uniform_filter(nx, size) ** 2)
+
+    np.savez_compressed(os.path.join(HERE, "smo_scipy.npz"), img=img, smo_s0_k7=smo_scipy(img, 0.0, 7),
+                        smo_s15_k7=smo_scipy(img, 1.5, 7), smo_s0_k5=smo_scipy(img, 0.0, 5))
+
+
+def golden_xcorr():
+    """skimage 0.18 phase_cross_correlation (un-normalised cross-correlation + upsampled DFT)."""
+    pairs, coarse, fine = [], [], []
+    for integer in (True, False):
+        st, dr = synth.make_stack(4, 1, 1, 128, 128, n_cells=12, integer_drift=integer, seed=3)
+        for f in range(1, 4):
+            ref, mov = st[0, 0, 0], st[f, 0, 0]
+            pairs.append(np.stack([ref, mov]))
+            # DC removed as the oracle does (the build zeroes the DC bin)
+            r = ref.astype(np.float64) - ref.mean()
+            m = mov.astype(np.float64) - mov.mean()
+            coarse.append(phase_cross_correlation(r, m, upsample_factor=1, return_error=False))
+            fine.append(phase_cross_correlation(r, m, upsample_factor=100, return_error=False))
+    np.savez_compressed(os.path.join(HERE, "xcorr_skimage.npz"), pairs=np.stack(pairs), coarse=np.array(coarse),
+                        fine=np.array(fine))
+
+
+if __name__ == "__main__":
+    golden_regionprops()
+    golden_shift()
+    golden_smo()
+    golden_xcorr()
+    print("golden fixtures written to", HERE)

@@ -1,0 +1,88 @@
+"""CPU: pins the oracle (oracle/ref_path.py) against the committed golden vectors in tests/golden/,
+which were produced by scikit-image 0.18.3 / scipy (tests/golden/make_golden.py) -- the closest
+executable ground truth available: the reference's own numeric dependencies (smo, pystackreg, cv2)
+are absent from the image and the reference ships no tests or fixtures."""
+import os
+
+import numpy as np
+
+from oracle import ref_path as O
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_measure_vs_regionprops():
+    d = np.load(os.path.join(G, "regionprops.npz"))
+    r = O.measure_labels(d["img"], d["labels"])
+    # regionprops never reports label 0; the reference drops the smallest value (0 here)
+    assert np.array_equal(r["ids"], d["ids"])
+    assert np.array_equal(r["area"], d["area"])
+    assert np.array_equal(r["centroid"], d["centroid"])           # coords.mean(0): same f64 arithmetic
+    assert np.array_equal(r["mean"], d["mean"])
+    lit = O.measure_labels_literal(d["img"], d["labels"])
+    assert np.array_equal(lit["mean"], d["mean"]) and np.array_equal(lit["area"], d["area"])
+
+
+def test_apply_shift_vs_scipy_ndimage():
+    d = np.load(os.path.join(G, "ndimage_shift.npz"))
+    for s, exp in zip(d["shifts"], d["out"]):
+        got = O.apply_shift_f64(d["img"], s[0], s[1])
+        assert np.abs(got - exp).max() < 1e-6
+        # u16 result: truncation of a value within 1e-6 of scipy's can differ only at integers
+        q = O.apply_shift(d["img"], s[0], s[1]).astype(np.int64)
+        assert np.abs(q - np.trunc(np.clip(exp, 0, 65535))).max() <= 1
+
+
+def test_smo_vs_scipy_filters():
+    d = np.load(os.path.join(G, "smo_scipy.npz"))
+    assert np.abs(O.smo_image(d["img"], 0.0, 7) - d["smo_s0_k7"]).max() < 1e-12
+    assert np.abs(O.smo_image(d["img"], 1.5, 7) - d["smo_s15_k7"]).max() < 1e-9
+    assert np.abs(O.smo_image(d["img"], 0.0, 5) - d["smo_s0_k5"]).max() < 1e-12
+
+
+def test_shift_estimate_vs_skimage():
+    d = np.load(os.path.join(G, "xcorr_skimage.npz"))
+    for pair, c, f in zip(d["pairs"], d["coarse"], d["fine"]):
+        assert np.array_equal(np.array(O.phase_shift(pair[0], pair[1], upsample=False)), c)
+        got = np.array(O.phase_shift(pair[0], pair[1]))
+        # skimage searches a 0.01 px grid, the oracle a 0.1 px grid + parabola: agree within 0.01 px
+        assert np.abs(got - f).max() <= 0.0101, (got, f)
+
+
+def test_bg_smo_integer_identity():
+    """out == trunc(max(img - med, 0)) with the median the oracle reports (half-integers included)"""
+    rng = np.random.default_rng(0)
+    img = (rng.poisson(30, size=(40, 64)) + 100).astype(np.uint16)
+    out, med2, n, mask = O.bg_smo(img, 0.08)
+    assert n == int(mask.sum()) and n > 0
+    assert med2 == int(round(2 * np.median(img[mask])))
+    assert np.array_equal(out, (np.maximum(2 * img.astype(np.int64) - med2, 0) >> 1).astype(np.uint16))
+
+
+def test_bg_manual_and_blur_known_answers():
+    img = np.arange(48, dtype=np.uint16).reshape(6, 8) * 10
+    out, bg = O.bg_manual(img, 1, 2, 2, 3)                # ROI values 100,110,180,190 -> mean 145
+    assert bg == 145 and out[0, 0] == 0 and out[5, 7] == 470 - 145
+    const = np.full((20, 20), 777, np.uint16)
+    assert np.array_equal(O.gauss_blur(const, (15, 15), 5.0), const)   # normalised taps keep constants
+    imp = np.zeros((21, 21), np.uint16)
+    imp[10, 10] = 60000
+    b = O.gauss_blur(imp, (5, 5), 1.0)
+    k = O.gauss_taps_cv(5, 1.0).astype(np.float64)
+    assert abs(int(b[10, 10]) - 60000 * k[2] * k[2]) <= 1 and b.sum() > 0
+    assert np.array_equal(b, b.T)
+
+
+def test_im_reg_stack_modes_recover_integer_drift():
+    from imageanalysis_pipeline_amd import synth
+    st, dr = synth.make_stack(4, 2, 1, 64, 64, n_cells=6, integer_drift=True, seed=2)
+    for mode in ("first", "previous"):
+        out, sh = O.im_reg_stack(st, 0, mode, upsample=False)
+        if mode == "first":
+            assert np.array_equal(sh, -dr)
+    try:
+        O.im_reg_stack(st, 0, "last")
+    except ValueError:
+        pass
+    else:
+        raise AssertionError("bad reg_ref must raise ValueError (utility.py:297-299)")
