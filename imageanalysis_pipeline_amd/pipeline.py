@@ -1,0 +1,438 @@
+"""Host-side mirror of the reference's interface for the hot path: same names, arguments, return
+values, side effects and error behaviour as ``pipeline/utility.py`` and ``pipeline/analysis.py``,
+with the per-file numpy/third-party loops replaced by ONE resident-stack call into libiap_hip.so.
+
+    Utility.smo_bg_sub / man_bg_sub / im_reg / blur_img   <- utility.py:242, 175, 274, 433
+    Utility.load_stack / load_mask / save_mask            <- utility.py:487, 558, 598 (layout contract)
+    Analysis.extract_channelData / extract_centroids      <- analysis.py:26, 114
+
+Drop-in use: ``Experiments`` / ``Exp_Indiv`` inherit these static methods instead of
+the reference's, e.g. ``from imageanalysis_pipeline_amd.pipeline import Utility`` in core.py.
+File I/O, the metadata pickle and the table post-processing (``transfo_df``) stay host side.
+Differences are limited to what the reference cannot do headless: ``man_bg_sub`` takes the ROI as
+an argument instead of opening an OpenCV window, and ``smo_bg_sub`` seeds the SMO null image.
+"""
+from __future__ import annotations
+
+import pickle
+from os import listdir, mkdir, scandir, sep
+from os.path import exists, isdir, join
+
+import numpy as np
+import pandas as pd
+import torch
+
+from . import ops
+from .tiffio import imread, imwrite
+
+
+def _device():
+    if not torch.cuda.is_available():
+        from ._lib import IapError
+        raise IapError("imageanalysis_pipeline_amd needs an MI355X: there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class Utility:
+    # ------------------------------------------------------------------ settings (utility.py:688-696)
+    @staticmethod
+    def open_exp_prop(exp_path):
+        with open(join(sep, exp_path + sep, "exp_properties.pickle"), "rb") as pickfile:
+            return pickle.load(pickfile)
+
+    @staticmethod
+    def save_exp_prop(exp_path, exp_prop):
+        with open(join(sep, exp_path + sep, "exp_properties.pickle"), "wb") as file:
+            pickle.dump(exp_prop, file, protocol=pickle.HIGHEST_PROTOCOL)
+
+    # ------------------------------------------------------------------ layout helpers
+    @staticmethod
+    def _plane_name(chan, f, z):
+        return chan + "_f%04d" % (f + 1) + "_z%04d" % (z + 1) + ".tif"      # utility.py:158-166
+
+    @staticmethod
+    def _folder_index(fold_path):
+        """{(prefix, frame, z): filename} built with ONE listdir (the reference re-lists and re-sorts
+        the folder for every (channel, frame): utility.py:513-517)."""
+        idx = {}
+        for im in sorted(listdir(fold_path)):
+            if not im.endswith(".tif"):
+                continue
+            parts = im[:-4].split("_")
+            try:
+                z = int(parts[-1][1:])
+                f = int(parts[-2][1:])
+            except (ValueError, IndexError):
+                continue
+            idx[("_".join(parts[:-2]), f - 1, z - 1)] = im
+        return idx
+
+    @staticmethod
+    def load_stack(imgFold_path, channel_list=None, input_range=None):
+        """utility.py:487-524: (C,T,Z,Y,X) -> squeeze -> channel-last when more than one channel."""
+        exp_path = sep.join(imgFold_path.split(sep)[:-1])
+        exp_para = Utility.open_exp_prop(exp_path=exp_path)["metadata"]
+        if channel_list:
+            chan_lst = [channel_list] if type(channel_list) == str else channel_list
+        else:
+            chan_lst = exp_para["channel_list"]
+        frame_range = input_range if input_range else range(exp_para["t"])
+        idx = Utility._folder_index(imgFold_path)
+        exp_list = []
+        for chan in chan_lst:
+            chan_list = []
+            for frame in frame_range:
+                names = [v for (p, f, z), v in sorted(idx.items(), key=lambda kv: kv[0][2])
+                         if p.startswith(chan) and f == frame]
+                chan_list.append([imread(join(sep, imgFold_path + sep, n)) for n in names])
+            exp_list.append(chan_list)
+        if len(chan_lst) == 1:
+            return np.squeeze(np.stack(exp_list))
+        return np.moveaxis(np.squeeze(np.stack(exp_list)), [0], [-1])
+
+    @staticmethod
+    def load_mask(maskFold_path, channel_seg, mask_shape=None, input_range=None, do_log=True):
+        """utility.py:558-595."""
+        if not any(channel_seg in file for file in listdir(maskFold_path)):
+            raise AttributeError(f"No masks was found for the selected segmented channel: {channel_seg}")
+        exp_path = sep.join(maskFold_path.split(sep)[:-1])
+        exp_para = Utility.open_exp_prop(exp_path=exp_path)["metadata"]
+        if input_range:
+            if not isinstance(input_range, list):
+                raise TypeError("input range must be a list")
+            frame_range = input_range
+        else:
+            frame_range = list(range(exp_para["t"]))
+        if mask_shape and type(mask_shape) != str:
+            raise TypeError("mask_shape must be a string")
+        if do_log:
+            print(f"---> Loading frames {frame_range} of masks from '{maskFold_path}'")
+        prefix = "mask_%s%s" % (channel_seg, mask_shape if mask_shape else "")
+        idx = Utility._folder_index(maskFold_path)
+        exp_list = []
+        for f in frame_range:
+            for (p, ff, z), name in sorted(idx.items(), key=lambda kv: (kv[0][1], kv[0][2])):
+                if ff == f and p == prefix:
+                    exp_list.append(imread(join(sep, maskFold_path + sep, name)))
+        return np.squeeze(np.stack(exp_list))
+
+    @staticmethod
+    def save_mask(mask_stack, save_dir, batch, z_size, frames, chan_seg, motif=None):
+        """utility.py:598-618."""
+        if isinstance(mask_stack, np.ndarray):
+            mask_stack = [mask_stack] if (mask_stack.ndim == 2 or frames == 1) else [m for m in mask_stack]
+        motif = "_" + motif if motif else ""
+        for i, f in enumerate(batch):
+            for z in range(z_size):
+                name = f"mask_{chan_seg}{motif}" + "_f%04d" % (f + 1) + "_z%04d" % (z + 1) + ".tif"
+                plane = mask_stack[i] if z_size == 1 else mask_stack[i][z, ...]
+                imwrite(join(sep, save_dir + sep, name), plane.astype(np.uint16))
+
+    @staticmethod
+    def _read_folder_stack(fold_path, exp_para, prefix_of=lambda c: c, channels=None):
+        """Whole folder -> u16 (T, C, Z, Y, X) host array (planar, the on-disk layout)."""
+        chans = channels if channels is not None else exp_para["channel_list"]
+        t, z = exp_para["t"], exp_para["z"]
+        idx = Utility._folder_index(fold_path)
+        first = imread(join(sep, fold_path + sep, next(iter(idx.values()))))
+        y, x = first.shape
+        stack = np.empty((t, len(chans), z, y, x), dtype=np.uint16)
+        for ci, chan in enumerate(chans):
+            for f in range(t):
+                for k in range(z):
+                    name = idx.get((prefix_of(chan), f, k))
+                    if name is None:
+                        raise FileNotFoundError(f"{fold_path}: missing plane {prefix_of(chan)} f={f + 1} z={k + 1}")
+                    stack[f, ci, k] = imread(join(sep, fold_path + sep, name))
+        return stack
+
+    @staticmethod
+    def _write_folder_stack(fold_path, stack, channels):
+        t, c, z = stack.shape[:3]
+        for ci, chan in enumerate(channels):
+            for f in range(t):
+                for k in range(z):
+                    imwrite(join(sep, fold_path + sep, Utility._plane_name(chan, f, k)), stack[f, ci, k])
+
+    # ------------------------------------------------------------------ background (utility.py:175-270)
+    @staticmethod
+    def smo_bg_sub(imgFold_path, sigma=0.0, size=7, seed=0):
+        print(f"--> Applying 'Auto' background substraction on {imgFold_path} with: sigma={sigma} and size={size}")
+        exp_path = sep.join(imgFold_path.split(sep)[:-1])
+        exp_prop = Utility.open_exp_prop(exp_path=exp_path)
+        exp_para = exp_prop["metadata"]
+        dev = _device()
+        # every .tif of the folder, whatever its channel (utility.py:255-256), in one resident batch
+        names = [f for f in sorted(listdir(imgFold_path)) if f.endswith(".tif")]
+        if names:
+            planes = np.stack([imread(join(sep, imgFold_path + sep, f)) for f in names]).astype(np.uint16)
+            thr = ops.smo_threshold(planes.shape[-2:], sigma=sigma, size=size, seed=seed, device=dev)
+            d = ops.to_device_u16(planes, dev)
+            out, _, _ = ops.bg_smo(d, thr, sigma=sigma, size=size, out=d)     # in place, as the reference
+            res = ops.to_numpy_u16(out)
+            for f, plane in zip(names, res):
+                imwrite(join(sep, imgFold_path + sep, f), plane)
+        exp_prop["fct_inputs"]["smo_bg_sub"] = {"imgFold_path": imgFold_path, "smo_sigma": sigma, "smo_size": size}
+        exp_prop["img_preProcess"]["bg_sub"] = "Auto"
+        Utility.save_exp_prop(exp_path=exp_path, exp_prop=exp_prop)
+        return exp_prop
+
+    @staticmethod
+    def man_bg_sub(imgFold_path, roi=None):
+        """utility.py:175-239 without the OpenCV window: ``roi`` = ((row0, col0), (row1, col1)) in image
+        pixels, inclusive (what draw.rectangle receives at utility.py:210); ``None`` = 'skip' pressed."""
+        print(f"--> Applying 'Manual' background substraction on {imgFold_path}")
+        exp_path = sep.join(imgFold_path.split(sep)[:-1])
+        exp_prop = Utility.open_exp_prop(exp_path=exp_path)
+        exp_para = exp_prop["metadata"]
+        if roi:
+            (r0, c0), (r1, c1) = roi
+            r0, r1 = sorted((int(r0), int(r1)))
+            c0, c1 = sorted((int(c0), int(c1)))
+            dev = _device()
+            stack = Utility._read_folder_stack(imgFold_path, exp_para)
+            out, _ = ops.bg_manual(ops.to_device_u16(stack, dev), (r0, c0, r1, c1))
+            Utility._write_folder_stack(imgFold_path, ops.to_numpy_u16(out), exp_para["channel_list"])
+            exp_prop["fct_inputs"]["man_bg_sub"] = {"imgFold_path": imgFold_path}
+            exp_prop["img_preProcess"]["bg_sub"] = "Manual"
+            Utility.save_exp_prop(exp_path=exp_path, exp_prop=exp_prop)
+        return exp_prop
+
+    # ------------------------------------------------------------------ registration (utility.py:274-430)
+    @staticmethod
+    def im_reg(imgFold_path, reg_channel, reg_mtd, chan_shift, reg_ref, reg_ow):
+        exp_path = sep.join(imgFold_path.split(sep)[:-1])
+        exp_prop = Utility.open_exp_prop(exp_path=exp_path)
+        exp_para = exp_prop["metadata"]
+        if exp_para["t"] == 1:
+            print(f"--> {imgFold_path} CANNOT be registrated as it is NOT a time sequence")
+            exp_prop["img_preProcess"]["reg"] = False
+        else:
+            exp_prop["img_preProcess"]["reg"] = True
+            reg_im_path = imgFold_path + "_Registered"
+            if not isdir(reg_im_path):
+                mkdir(reg_im_path)
+            if any(scandir(reg_im_path)) and not reg_ow:
+                print(f"--> {imgFold_path} are already registered")
+            else:
+                ref_list = ["first", "previous", "mean"]
+                if reg_ref not in ref_list:
+                    raise ValueError(f"{reg_ref} is not valid. Please only put {ref_list}")
+                mtd_list = ["translation", "rigid_body", "scaled_rotation", "affine", "bilinear"]
+                if reg_mtd not in mtd_list:
+                    raise ValueError(f"{reg_mtd} is not valid. Please only put {mtd_list}")
+                if reg_mtd != "translation":
+                    raise NotImplementedError(f"reg_mtd='{reg_mtd}': the MI355X path implements the reference's "
+                                              "default 'translation' (core.py:77); other StackReg modes stay in the reference")
+                print(f"--> Registering {imgFold_path} with method '{reg_mtd}' and reference '{reg_ref}'")
+                # chan_shift: the reference's channel-shift pass writes files that the reg_ref pass then
+                # overwrites from the raw folder (utility.py:313-330 vs 338-355), so it has no observable
+                # effect on the output; it is therefore not run here.
+                chans = exp_para["channel_list"]
+                dev = _device()
+                stack = Utility._read_folder_stack(imgFold_path, exp_para)
+                out, shifts = ops.im_reg(ops.to_device_u16(stack, dev), chans.index(reg_channel), reg_ref)
+                Utility._write_folder_stack(reg_im_path, ops.to_numpy_u16(out), chans)
+                exp_prop["fct_inputs"]["im_reg"] = {"imgFold_path": imgFold_path, "reg_channel": reg_channel,
+                                                    "reg_mtd": reg_mtd, "reg_ref": reg_ref, "reg_ow": reg_ow}
+                if "channel_seg" in exp_prop:
+                    if "Images_Registered" in exp_prop["channel_seg"]:
+                        if reg_channel not in exp_prop["channel_seg"]["Images_Registered"]:
+                            exp_prop["channel_seg"]["Images_Registered"].append(reg_channel)
+                    else:
+                        exp_prop["channel_seg"]["Images_Registered"] = [reg_channel]
+                else:
+                    exp_prop["channel_seg"] = {"Images_Registered": [reg_channel]}
+        Utility.save_exp_prop(exp_path=exp_path, exp_prop=exp_prop)
+        return exp_prop
+
+    # ------------------------------------------------------------------ blur (utility.py:433-468)
+    @staticmethod
+    def blur_img(imgFold_path, blur_kernel, blur_sigma, blur_ow):
+        if type(blur_kernel) != tuple:
+            raise TypeError("The input 'blur_kernel' must be a tuple: (int,int)")
+        if not all(i % 2 != 0 for i in blur_kernel) and not all(i >= 3 for i in blur_kernel):
+            print("The input 'blur_kernel' must contain 2 odd intengers greater or equal to 3")
+        exp_path = sep.join(imgFold_path.split(sep)[:-1])
+        exp_prop = Utility.open_exp_prop(exp_path=exp_path)
+        blur_img_path = join(sep, exp_path + sep, "Images_Blured")
+        if not isdir(blur_img_path):
+            mkdir(blur_img_path)
+        if any(scandir(blur_img_path)) and not blur_ow:
+            print("-> Images are already blured")
+        else:
+            print(f"-> Bluring images using a kernel of {blur_kernel} and sigma of {blur_sigma}")
+            names = [f for f in sorted(listdir(imgFold_path)) if f.endswith(".tif")]
+            if names:
+                dev = _device()
+                planes = np.stack([imread(join(sep, imgFold_path + sep, f)) for f in names]).astype(np.uint16)
+                res = ops.to_numpy_u16(ops.gauss_blur(ops.to_device_u16(planes, dev), blur_kernel, blur_sigma))
+                for f, plane in zip(names, res):
+                    imwrite(join(sep, blur_img_path + sep, f), plane)
+            exp_prop["fct_inputs"]["blur_img"] = {"imgFold_path": imgFold_path, "blur_kernel": blur_kernel,
+                                                  "blur_sigma": blur_sigma, "blur_ow": blur_ow}
+            exp_prop["img_preProcess"]["blur"] = True
+            Utility.save_exp_prop(exp_path=exp_path, exp_prop=exp_prop)
+        return exp_prop, blur_img_path
+
+    @staticmethod
+    def transfo_df(df, channel_list, stim_time=None, start_baseline=0, posCont_time=None, signal_type="linear"):
+        """Table post-processing (ratios, deltaF, outliers: utility.py:924-1046) is out of the hot path and
+        stays in the reference; subclasses that inherit the reference's Utility override this no-op."""
+        if signal_type not in ["linear", "ocsillatory"]:
+            raise AttributeError(f"signal_type can only be {['linear', 'ocsillatory']}")
+        return df
+
+
+class Analysis(Utility):
+    """analysis.py:9-190 for the two hot methods; constructor as Exp_Indiv (experiments.py:19-37) + Analysis."""
+
+    def __init__(self, exp_path, channel_seg, interval=None, tag=None, tag_ow=False):
+        self.exp_path = exp_path
+        if exists(join(sep, self.exp_path + sep, "exp_properties.pickle")):
+            self.exp_prop = Analysis.open_exp_prop(exp_path=self.exp_path)
+            if "img_process" not in self.exp_prop:
+                self.exp_prop["img_process"] = {}
+        else:
+            raise ValueError(f"{self.exp_path} has no preprocessed experiment. Please run the Experiments class first")
+        exp_para = self.exp_prop["metadata"]
+        self.channel_list = exp_para["channel_list"]
+        self.channel_seg = channel_seg
+        self.x_size, self.y_size, self.z_size = exp_para["x"], exp_para["y"], exp_para["z"]
+        self.frames, self.chan_numb = exp_para["t"], exp_para["c"]
+        if tag:
+            if not isinstance(tag, dict):
+                raise TypeError("tag needs to be a dictionary with 'exp_path' as key and 'tag' as value")
+            self.tag = tag[exp_path]
+        elif tag_ow:
+            print("Tags were overwritten")
+            self.tag = exp_path.split(sep)[-2]
+        else:
+            self.tag = exp_para["tag"]
+        self.pixSize = exp_para.get("pixel_microns")
+        self.interval = interval if interval else exp_para["interval_sec"]
+        self.ts = [0.0] + list(np.round(a=np.linspace(self.interval, self.interval * (self.frames - 1), self.frames - 1) / 60,
+                                        decimals=2))
+
+    # -- helpers ---------------------------------------------------------------------------------
+    def _exp_name(self):
+        split_path = self.exp_path.split(sep)[-1].split("_")
+        return "_".join([self.tag, split_path[0], split_path[-1]])
+
+    def _mask_sets(self, maskFold, centroid=False):
+        """(mask folder, channel, shape-suffix) triplets exactly as analysis.py:36-59 / 124-137."""
+        if maskFold == "Masks_Compartment":
+            chan_keys = self.exp_prop["channel_seg"]["Masks_Compartment"]
+            shapes = ["cyto"] if centroid else ["_mb", "_cyto", "_full"]
+            return [(join(sep, self.exp_path + sep, maskFold), chan, s) for chan in chan_keys for s in shapes]
+        if maskFold == "Masks_Class":
+            chan_keys = self.exp_prop["channel_seg"]["Masks_Class"]
+            folder = join(sep, self.exp_path + sep, self.exp_prop["masks_process"]["classification"]["folder"])
+            return [(folder, chan_keys[0], None)]
+        chan_keys = self.exp_prop["channel_seg"][maskFold]
+        return [(join(sep, self.exp_path + sep, maskFold), chan, None) for chan in chan_keys]
+
+    def _label_stack(self, folder, chan, shape):
+        """u16 (T, Z, Y, X) from mask_<chan>[<shape>]_fNNNN_zNNNN.tif (utility.py:590-593)."""
+        prefix = "mask_%s%s" % (chan, shape if shape else "")
+        if not any(chan in file for file in listdir(folder)):
+            raise AttributeError(f"No masks was found for the selected segmented channel: {chan}")
+        return Utility._read_folder_stack(folder, self.exp_prop["metadata"], prefix_of=lambda c: prefix,
+                                          channels=[chan])[:, 0]
+
+    def _measure(self, img_stack, lab_stack):
+        dev = _device()
+        img = ops.to_device_u16(img_stack, dev) if img_stack is not None else None
+        lab = ops.to_device_u16(lab_stack, dev)
+        if img is None:  # centroids only: a zero image channel keeps one code path
+            img = torch.zeros((lab.shape[0], 1) + tuple(lab.shape[1:]), dtype=torch.uint16, device=dev)
+        return ops.measure_labels(img, lab)
+
+    # -- analysis.py:26-112 ----------------------------------------------------------------------
+    def extract_channelData(self, imgFold, maskFold, stim_time=None, start_baseline=0, posCont_time=None,
+                            channel_seg=None, df_ow=False, signal_type="linear"):
+        fi = self.exp_prop["fct_inputs"]
+        if "extract_channelData" not in fi or fi["extract_channelData"]["maskFold"] != maskFold or df_ow:
+            print(f"---> Extracting channel data with {maskFold}")
+            sets = self._mask_sets(maskFold)
+            if maskFold == "Masks_Compartment":
+                mask_keys = [f"{chan}{shape}" for chan in self.channel_list for shape in ["_mb", "_cyto", "_full"]]
+            else:
+                mask_keys = [chan for chan in self.channel_list]
+            keys = ["cell", "frames", "time", "mask_chan", "tag", "exp"] + mask_keys
+            exp_name = self._exp_name()
+            img_stack = Utility._read_folder_stack(join(sep, self.exp_path + sep, imgFold), self.exp_prop["metadata"])
+            df = pd.DataFrame()
+            by_chan = {}
+            for folder, chan, shape in sets:
+                by_chan.setdefault(chan, []).append((folder, shape))
+            for chan, lst in by_chan.items():
+                d = {k: [] for k in keys}
+                tables = [self._measure(img_stack, self._label_stack(folder, chan, shape)) for folder, shape in lst]
+                for f, t in enumerate(self.ts):
+                    for (folder, shape), tab in zip(lst, tables):
+                        tb = tab[f]
+                        for i, obj in enumerate(tb["ids"]):
+                            d["cell"].append(f"{exp_name}_{chan}_cell{obj}")
+                            d["mask_chan"].append(chan)
+                            d["tag"].append(self.tag)
+                            d["exp"].append(exp_name)
+                            d["frames"].append(f + 1)
+                            d["time"].append(t)
+                            for ci, ch in enumerate(self.channel_list):
+                                for name in mask_keys:
+                                    if ch in name:                       # analysis.py:96-98, incl. its substring match
+                                        d[name].append(tb["mean"][i, ci])
+                df = pd.concat([df, pd.DataFrame.from_dict(d)], ignore_index=True)
+            self.df_analysis = type(self).transfo_df(df=df, channel_list=mask_keys, stim_time=stim_time,
+                                                     start_baseline=start_baseline, posCont_time=posCont_time,
+                                                     signal_type=signal_type)
+            self.exp_prop["df_analysis"] = self.df_analysis
+            fi["extract_channelData"] = {"imgFold": imgFold, "maskFold": maskFold, "channel_seg": channel_seg}
+            Analysis.save_exp_prop(exp_path=self.exp_path, exp_prop=self.exp_prop)
+            df.to_csv(join(sep, self.exp_path + sep, "df_analysis.csv"), index=False)
+        else:
+            print(f"---> Channel data are already extracted with {maskFold}")
+            self.df_analysis = pd.read_csv(join(sep, self.exp_path + sep, "df_analysis.csv"))
+
+    # -- analysis.py:114-190 ---------------------------------------------------------------------
+    def extract_centroids(self, maskFold, channel_seg=None, df_ow=False):
+        fi = self.exp_prop["fct_inputs"]
+        if "extract_centroids" not in fi or fi["extract_centroids"]["maskFold"] != maskFold or df_ow:
+            print(f"---> Extracting centroids for {maskFold}")
+            axes_keys = ["y", "x"] if self.z_size == 1 else ["y", "x", "z"]
+            keys = ["cell", "frames", "time", "mask_chan", "mask_ID"] + axes_keys
+            exp_name = self._exp_name()
+            df = pd.DataFrame()
+            for folder, chan, shape in self._mask_sets(maskFold, centroid=True):
+                d = {k: [] for k in keys}
+                tab = self._measure(None, self._label_stack(folder, chan, shape))
+                for f, t in enumerate(self.ts):
+                    tb = tab[f]
+                    for i, obj in enumerate(tb["ids"]):
+                        d["cell"].append(f"{exp_name}_{chan}_cell{obj}")
+                        d["mask_chan"].append(chan)
+                        d["frames"].append(f + 1)
+                        d["time"].append(t)
+                        d["mask_ID"].append(obj)
+                        c = tb["centroid_rne"][i]
+                        if self.z_size == 1:
+                            d["y"].append(int(c[0]))
+                            d["x"].append(int(c[1]))
+                        else:
+                            d["z"].append(int(c[0]))
+                            d["y"].append(int(c[1]))
+                            d["x"].append(int(c[2]))
+                df = pd.concat([df, pd.DataFrame.from_dict(d)], ignore_index=True)
+            if not hasattr(self, "df_analysis"):
+                self.df_analysis = pd.DataFrame.from_dict(df)
+            else:
+                self.df_analysis = pd.merge(self.df_analysis, pd.DataFrame.from_dict(df),
+                                            on=["cell", "frames", "time", "mask_chan"])
+            self.exp_prop["df_analysis"] = self.df_analysis
+            fi["extract_centroids"] = {"maskFold": maskFold, "channel_seg": channel_seg}
+            Analysis.save_exp_prop(exp_path=self.exp_path, exp_prop=self.exp_prop)
+            self.df_analysis.to_csv(join(sep, self.exp_path + sep, "df_analysis.csv"), index=False)
+        else:
+            print(f"---> Centroids are already extracted for {maskFold}")
+            self.df_analysis = pd.read_csv(join(sep, self.exp_path + sep, "df_analysis.csv"))

@@ -1,0 +1,77 @@
+"""Minimal baseline-TIFF reader/writer for the planes the reference exchanges on disk:
+single-page, uncompressed, 16-bit (or 8/32-bit) grayscale, as written by
+``tifffile.imwrite(path, plane.astype(np.uint16))`` (utility.py:166, 264, 355, 616).
+
+File I/O stays in the reference (north_star); this module only exists so that the folder-level
+shim (pipeline.py) works where ``tifffile`` is not installed.  When ``tifffile`` is importable it
+is used instead.
+"""
+from __future__ import annotations
+
+import struct
+
+import numpy as np
+
+try:  # pragma: no cover - depends on the environment
+    import tifffile as _tf
+except Exception:  # noqa: BLE001
+    _tf = None
+
+_TYPES = {1: ("B", 1), 2: ("c", 1), 3: ("H", 2), 4: ("I", 4), 5: ("II", 8), 16: ("Q", 8)}
+
+
+def imread(path: str) -> np.ndarray:
+    if _tf is not None:
+        return _tf.imread(path)
+    with open(path, "rb") as fh:
+        buf = fh.read()
+    bo = {b"II": "<", b"MM": ">"}.get(buf[:2])
+    if bo is None or struct.unpack(bo + "H", buf[2:4])[0] != 42:
+        raise ValueError(f"{path}: not a classic TIFF file")
+    (ifd,) = struct.unpack(bo + "I", buf[4:8])
+    (n,) = struct.unpack(bo + "H", buf[ifd:ifd + 2])
+    tags = {}
+    for i in range(n):
+        e = ifd + 2 + 12 * i
+        tag, typ, cnt = struct.unpack(bo + "HHI", buf[e:e + 8])
+        fmt, size = _TYPES.get(typ, ("B", 1))
+        if typ == 5:
+            continue
+        total = size * cnt
+        off = e + 8 if total <= 4 else struct.unpack(bo + "I", buf[e + 8:e + 12])[0]
+        tags[tag] = struct.unpack(bo + fmt * cnt, buf[off:off + total])
+    w, h = tags[256][0], tags[257][0]
+    bits = tags.get(258, (1,))[0]
+    if tags.get(259, (1,))[0] != 1:
+        raise ValueError(f"{path}: compressed TIFF is not supported by the built-in reader (install tifffile)")
+    if tags.get(277, (1,))[0] != 1:
+        raise ValueError(f"{path}: only single-sample (grayscale) planes are supported")
+    sfmt = tags.get(339, (1,))[0]
+    dt = {(8, 1): "u1", (16, 1): "u2", (32, 1): "u4", (16, 2): "i2", (32, 3): "f4"}.get((bits, sfmt))
+    if dt is None:
+        raise ValueError(f"{path}: unsupported sample format bits={bits} format={sfmt}")
+    offs, cnts = tags[273], tags[279]
+    data = b"".join(buf[o:o + c] for o, c in zip(offs, cnts))
+    return np.frombuffer(data, dtype=np.dtype(bo + dt), count=w * h).reshape(h, w).astype(np.dtype(dt))
+
+
+def imwrite(path: str, a: np.ndarray) -> None:
+    if _tf is not None:
+        _tf.imwrite(path, a)
+        return
+    a = np.ascontiguousarray(a)
+    if a.ndim != 2 or a.dtype not in (np.uint8, np.uint16, np.uint32, np.float32):
+        raise ValueError("built-in TIFF writer handles 2-D uint8/uint16/uint32/float32 planes")
+    h, w = a.shape
+    data = a.astype(a.dtype.newbyteorder("<")).tobytes()
+    sfmt = 3 if a.dtype == np.float32 else 1
+    entries = [(256, 4, w), (257, 4, h), (258, 3, a.dtype.itemsize * 8), (259, 3, 1), (262, 3, 1),
+               (273, 4, 8), (277, 3, 1), (278, 4, h), (279, 4, len(data)), (339, 3, sfmt)]
+    ifd_off = 8 + len(data) + (len(data) & 1)
+    out = bytearray(b"II" + struct.pack("<HI", 42, ifd_off) + data + (b"\0" if len(data) & 1 else b""))
+    out += struct.pack("<H", len(entries))
+    for tag, typ, val in entries:
+        out += struct.pack("<HHI", tag, typ, 1) + (struct.pack("<HH", val, 0) if typ == 3 else struct.pack("<I", val))
+    out += struct.pack("<I", 0)
+    with open(path, "wb") as fh:
+        fh.write(bytes(out))

@@ -1,0 +1,80 @@
+"""CPU, world_size 2 over gloo: FOV sharding and the variable-length table gather (the only
+collective of the path; core.py:336 pd.concat counterpart)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from imageanalysis_pipeline_amd.distributed import gather_rows, pack_rows, shard_fovs
+
+
+def test_shard_fovs_partitions_exactly():
+    for n in (0, 1, 7, 64):
+        for world in (1, 2, 3, 8):
+            got = [i for r in range(world) for i in shard_fovs(n, r, world)]
+            assert got == list(range(n))
+            sizes = [len(shard_fovs(n, r, world)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_pack_rows_layout():
+    area = torch.tensor([[5, 0, 3], [0, 2, 0]])
+    mean = torch.arange(12, dtype=torch.float64).reshape(2, 3, 2)
+    cen = torch.arange(18, dtype=torch.float64).reshape(2, 3, 3) + 100
+    rows = pack_rows((area, mean, cen), fov=4)
+    # label 0 of frame 0 dropped; rows: (frame0,label2), (frame1,label1)
+    assert rows.shape == (2, 4 + 2 + 3)
+    assert rows[:, :4].tolist() == [[4, 0, 2, 3], [4, 1, 1, 2]]
+    assert rows[0, 4:6].tolist() == mean[0, 2].tolist() and rows[1, 6:].tolist() == cen[1, 1].tolist()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_fov = 5
+        mine = []
+        for fov in shard_fovs(n_fov, rank, world):
+            g = torch.Generator().manual_seed(fov)
+            k = 3 + fov                                     # ragged: every FOV has another row count
+            mine.append(torch.cat([torch.full((k, 1), float(fov), dtype=torch.float64),
+                                   torch.rand((k, 8), generator=g, dtype=torch.float64)], 1))
+        rows = torch.cat(mine, 0)
+        allrows = gather_rows(rows)
+        empty = gather_rows(torch.zeros((0, 9), dtype=torch.float64) if rank == 1 else rows)   # one rank empty
+        q.put((rank, allrows.numpy(), empty.shape[0]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_rows_world2_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    exp = []
+    for fov in range(5):
+        g = torch.Generator().manual_seed(fov)
+        k = 3 + fov
+        exp.append(np.concatenate([np.full((k, 1), float(fov)), torch.rand((k, 8), generator=g, dtype=torch.float64).numpy()], 1))
+    exp = np.concatenate(exp, 0)
+    for rank, rows, n_empty in res:
+        assert np.array_equal(rows, exp)                    # rank order == FOV order, identical on every rank
+        assert n_empty == sum(3 + f for f in shard_fovs(5, 0, 2))

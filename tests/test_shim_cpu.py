@@ -1,0 +1,97 @@
+"""CPU: host logic of the reference-interface shim that needs no GPU -- TIFF round trip, the
+load_stack / load_mask / save_mask layout contract (utility.py:487-524, 558-618) and the error
+conventions."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from imageanalysis_pipeline_amd import tiffio
+from imageanalysis_pipeline_amd.pipeline import Analysis, Utility
+
+
+def make_exp(tmp, t=3, c=2, z=1, y=16, x=24, chans=("GFP", "RFP"), seed=0):
+    exp = os.path.join(str(tmp), "cond", "s1_exp")
+    os.makedirs(os.path.join(exp, "Images"))
+    rng = np.random.default_rng(seed)
+    stack = rng.integers(0, 65536, size=(t, c, z, y, x)).astype(np.uint16)
+    for ci, ch in enumerate(chans):
+        for f in range(t):
+            for k in range(z):
+                tiffio.imwrite(os.path.join(exp, "Images", "%s_f%04d_z%04d.tif" % (ch, f + 1, k + 1)), stack[f, ci, k])
+    prop = {"metadata": {"t": t, "z": z, "c": c, "x": x, "y": y, "channel_list": list(chans), "tag": "cond",
+                         "interval_sec": 60, "pixel_microns": 0.5, "v_idx": 1},
+            "img_preProcess": {"bg_sub": "None", "reg": False, "blur": False}, "fct_inputs": {}, "masks_process": {},
+            "status": "active"}
+    with open(os.path.join(exp, "exp_properties.pickle"), "wb") as fh:
+        pickle.dump(prop, fh)
+    return exp, stack
+
+
+def test_tiff_round_trip(tmp_path):
+    for dt in (np.uint8, np.uint16, np.float32):
+        a = (np.random.default_rng(1).random((7, 9)) * 200).astype(dt)
+        p = str(tmp_path / f"a_{np.dtype(dt).name}.tif")
+        tiffio.imwrite(p, a)
+        b = tiffio.imread(p)
+        assert b.dtype == a.dtype and np.array_equal(a, b)
+
+
+def test_load_stack_layout(tmp_path):
+    exp, stack = make_exp(tmp_path)
+    img = os.path.join(exp, "Images")
+    full = Utility.load_stack(img)                                   # (T, Y, X, C): channel-last view
+    assert full.shape == (3, 16, 24, 2) and np.array_equal(full[..., 1], stack[:, 1, 0])
+    one = Utility.load_stack(img, channel_list="RFP", input_range=[1])   # squeeze drops T and C
+    assert one.shape == (16, 24) and np.array_equal(one, stack[1, 1, 0])
+
+
+def test_load_stack_zstack(tmp_path):
+    exp, stack = make_exp(tmp_path, t=2, c=1, z=3, chans=("GFP",))
+    s = Utility.load_stack(os.path.join(exp, "Images"))
+    assert s.shape == (2, 3, 16, 24) and np.array_equal(s, stack[:, 0])
+
+
+def test_save_and_load_mask(tmp_path):
+    exp, _ = make_exp(tmp_path)
+    mdir = os.path.join(exp, "Masks_CP")
+    os.makedirs(mdir)
+    masks = np.random.default_rng(2).integers(0, 5, size=(3, 16, 24)).astype(np.uint16)
+    Utility.save_mask(masks, mdir, batch=[0, 1, 2], z_size=1, frames=3, chan_seg="GFP")
+    assert sorted(os.listdir(mdir))[0] == "mask_GFP_f0001_z0001.tif"
+    back = Utility.load_mask(mdir, "GFP", do_log=False)
+    assert np.array_equal(back, masks)
+    assert np.array_equal(Utility.load_mask(mdir, "GFP", input_range=[2], do_log=False), masks[2])
+    with pytest.raises(AttributeError):
+        Utility.load_mask(mdir, "BFP")                               # utility.py:559-560
+    with pytest.raises(TypeError):
+        Utility.load_mask(mdir, "GFP", input_range=2)                # utility.py:568-569
+
+
+def test_error_conventions_without_gpu(tmp_path):
+    exp, _ = make_exp(tmp_path)
+    img = os.path.join(exp, "Images")
+    with pytest.raises(ValueError):
+        Utility.im_reg(img, "GFP", "translation", False, "last", True)     # utility.py:297-299
+    with pytest.raises(ValueError):
+        Utility.im_reg(img, "GFP", "warp", False, "first", True)           # utility.py:300-302
+    with pytest.raises(TypeError):
+        Utility.blur_img(img, [15, 15], 5, True)                           # utility.py:435-436
+    with pytest.raises(ValueError):
+        Analysis(os.path.join(str(tmp_path), "nowhere"), "GFP")            # experiments.py:26
+    with pytest.raises(TypeError):
+        Analysis(exp, "GFP", tag="x")                                      # analysis.py:13
+
+
+def test_single_frame_registration_is_a_noop(tmp_path):
+    exp, _ = make_exp(tmp_path, t=1)
+    prop = Utility.im_reg(os.path.join(exp, "Images"), "GFP", "translation", False, "mean", False)
+    assert prop["img_preProcess"]["reg"] is False                          # utility.py:281-283
+    assert not os.path.isdir(os.path.join(exp, "Images_Registered"))
+
+
+def test_analysis_time_axis(tmp_path):
+    exp, _ = make_exp(tmp_path, t=4)
+    a = Analysis(exp, "GFP")
+    assert a.ts == [0.0, 1.0, 2.0, 3.0] and a.frames == 4 and a.tag == "cond"

@@ -1,0 +1,106 @@
+"""GPU: the folder-level shim (imageanalysis_pipeline_amd.pipeline) end to end on a synthetic
+experiment folder, read like the reference's own call sequence (core.py:105-112, 328-330):
+smo_bg_sub -> im_reg -> extract_channelData -> extract_centroids."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from oracle import ref_path as O
+from imageanalysis_pipeline_amd import synth, tiffio
+from imageanalysis_pipeline_amd.pipeline import Analysis, Utility
+from test_shim_cpu import make_exp
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_stack(exp, stack, chans):
+    for ci, ch in enumerate(chans):
+        for f in range(stack.shape[0]):
+            for k in range(stack.shape[2]):
+                tiffio.imwrite(os.path.join(exp, "Images", "%s_f%04d_z%04d.tif" % (ch, f + 1, k + 1)), stack[f, ci, k])
+
+
+def test_pre_process_and_analysis_sequence(dev, tmp_path):
+    from imageanalysis_pipeline_amd import ops
+    t, c, y, x = 4, 2, 128, 256
+    chans = ("GFP", "RFP")
+    exp, _ = make_exp(tmp_path, t=t, c=c, y=y, x=x, chans=chans)
+    stack, _ = synth.make_stack(t, c, 1, y, x, n_cells=10, integer_drift=True, seed=5)
+    _write_stack(exp, stack, chans)
+    img = os.path.join(exp, "Images")
+
+    # --- smo_bg_sub (utility.py:242-270): files overwritten in place, exp_prop updated
+    prop = Utility.smo_bg_sub(imgFold_path=img, sigma=0.0, size=7)
+    assert prop["img_preProcess"]["bg_sub"] == "Auto"
+    assert prop["fct_inputs"]["smo_bg_sub"] == {"imgFold_path": img, "smo_sigma": 0.0, "smo_size": 7}
+    thr = ops.smo_threshold((y, x), device=dev)
+    bg = np.empty_like(stack)
+    for f in range(t):
+        for ci, ch in enumerate(chans):
+            got = tiffio.imread(os.path.join(img, "%s_f%04d_z0001.tif" % (ch, f + 1)))
+            bg[f, ci, 0] = O.bg_smo(stack[f, ci, 0], thr)[0]
+            assert np.array_equal(got, bg[f, ci, 0])
+
+    # --- im_reg (utility.py:274-430)
+    prop = Utility.im_reg(imgFold_path=img, reg_channel="GFP", reg_mtd="translation", chan_shift=False,
+                          reg_ref="first", reg_ow=False)
+    assert prop["img_preProcess"]["reg"] is True and prop["channel_seg"] == {"Images_Registered": ["GFP"]}
+    regdir = img + "_Registered"
+    ereg, _ = O.im_reg_stack(bg, 0, "first")
+    reg = np.empty_like(stack)
+    for f in range(t):
+        for ci, ch in enumerate(chans):
+            reg[f, ci, 0] = tiffio.imread(os.path.join(regdir, "%s_f%04d_z0001.tif" % (ch, f + 1)))
+    assert np.abs(reg.astype(np.int64) - ereg.astype(np.int64)).max() <= 2
+    # second call without reg_ow: skipped (utility.py:292), files untouched
+    mt = os.path.getmtime(os.path.join(regdir, "GFP_f0001_z0001.tif"))
+    Utility.im_reg(img, "GFP", "translation", False, "first", False)
+    assert os.path.getmtime(os.path.join(regdir, "GFP_f0001_z0001.tif")) == mt
+
+    # --- masks + analysis (analysis.py:26-190)
+    mdir = os.path.join(exp, "Masks_CP")
+    os.makedirs(mdir)
+    lab = synth.make_labels(y, x, 10, seed=5)
+    Utility.save_mask(np.stack([lab] * t), mdir, batch=list(range(t)), z_size=1, frames=t, chan_seg="GFP")
+    prop = Utility.open_exp_prop(exp)
+    prop["channel_seg"]["Masks_CP"] = ["GFP"]
+    Utility.save_exp_prop(exp, prop)
+
+    a = Analysis(exp, "GFP")
+    a.extract_channelData(imgFold="Images_Registered", maskFold="Masks_CP")
+    a.extract_centroids(maskFold="Masks_CP")
+    df = a.df_analysis
+    assert list(df.columns) == ["cell", "frames", "time", "mask_chan", "tag", "exp", "GFP", "RFP", "mask_ID", "y", "x"]
+    # the reference's literal loops on the same files
+    rows = []
+    for f in range(t):
+        m = O.measure_labels_literal(reg[f, :, 0], lab)
+        for i, obj in enumerate(m["ids"]):
+            rows.append((f"cond_s1_exp_GFP_cell{obj}", f + 1, m["mean"][i, 0], m["mean"][i, 1], int(obj),
+                         int(m["centroid_rne"][i, 0]), int(m["centroid_rne"][i, 1])))
+    assert len(rows) == len(df)
+    for r, (_, d) in zip(rows, df.iterrows()):
+        assert d["cell"] == r[0] and d["frames"] == r[1] and d["mask_ID"] == r[4]
+        assert d["GFP"] == r[2] and d["RFP"] == r[3]                     # bit-exact float64
+        assert d["y"] == r[5] and d["x"] == r[6]
+    assert os.path.exists(os.path.join(exp, "df_analysis.csv"))
+    # cached second call reads the csv back (analysis.py:108-112)
+    b = Analysis(exp, "GFP")
+    b.extract_channelData(imgFold="Images_Registered", maskFold="Masks_CP")
+    assert len(b.df_analysis) == len(df)
+
+
+def test_man_bg_sub_and_blur(dev, tmp_path):
+    exp, stack = make_exp(tmp_path, t=2, c=2, y=40, x=64)
+    img = os.path.join(exp, "Images")
+    prop = Utility.man_bg_sub(img, roi=((2, 3), (20, 30)))
+    assert prop["img_preProcess"]["bg_sub"] == "Manual"
+    got = tiffio.imread(os.path.join(img, "RFP_f0002_z0001.tif"))
+    assert np.array_equal(got, O.bg_manual(stack[1, 1, 0], 2, 3, 20, 30)[0])
+    cur = tiffio.imread(os.path.join(img, "GFP_f0001_z0001.tif"))
+    prop, path = Utility.blur_img(img, (15, 15), 5, False)
+    assert path.endswith("Images_Blured") and prop["img_preProcess"]["blur"] is True
+    assert np.array_equal(tiffio.imread(os.path.join(path, "GFP_f0001_z0001.tif")), O.gauss_blur(cur, (15, 15), 5))
+    assert Utility.man_bg_sub(img, roi=None)["img_preProcess"]["bg_sub"] == "Manual"   # 'skip': untouched
