@@ -501,139 +501,248 @@ __global__ __launch_bounds__(256) void accum_planes_kernel(const uint16_t* __res
 }
 
 // Apply ------------------------------------------------------------------------------------
-constexpr int AP_R = 11;             // taps k = -AP_R .. AP_R+1
-constexpr int AP_TAPS = 2 * AP_R + 2;  // 24
-constexpr int AP_TX = 64, AP_TY = 64;
-constexpr int AP_W = AP_TX + AP_TAPS;  // staged tile width (88; one column spare)
-constexpr int AP_H = AP_TY + AP_TAPS;
+// out(y,x) = cubic B-spline interpolation of `in` at (y - dy, x - dx): scipy.ndimage.shift(order=3,
+// mode='constant', cval=0), i.e. spline coefficients c = (direct B-spline filter)^-1 s with mirror
+// boundary, then a 4-tap evaluation.  The inverse filter is the two-sided exponential
+// c[k] = c0 * sum_m z1^|m| s[k-m]  (z1 = sqrt(3)-2).  Per axis a thread evaluates a run of
+// neighbouring outputs: the causal and anti-causal sums are started with R+1 explicit taps
+// (truncation z1^(R+1) ~ 1.4e-7) and continued by the exact one-multiply recursions
+// C+[k+1] = s[k+1] + z1 C+[k],  C-[k-1] = s[k-1] + z1 C-[k]  -> ~12 FMA per sample instead of a
+// 24-tap FIR.  An axis whose shift is an integer bypasses the filter, so integer shifts are exact
+// copies.  Tiles are staged through LDS: aligned 16-byte loads for interior tiles, mirrored
+// scalar loads at the image border.
+constexpr int AP_R = 11;
+constexpr int AP_TX = 64;
+constexpr int AP_TW = 96;                   // staged columns: 12 aligned u16x8 vectors
+constexpr int AP_PITCH = 97;                // floats; == 1 mod 32 -> row-major lanes hit distinct banks
+constexpr int AP_RP = AP_TX + 1;            // pitch of the x-filtered tile
+constexpr float AP_Z1 = -0.26794919243112270647f;
 
 struct AxisParams {
-  int sh;      // integer part: source index = i + sh + k
-  int lo, hi;  // output indices with a source coordinate inside [0, n-1]
+  int sh;      // integer part of the source offset: i0 = i + sh
+  int lo, hi;  // output indices whose source coordinate lies inside [0, n-1]
+  int whole;   // 1: integer shift on this axis
+  float w[4];  // c0 * beta3(frac - j), j = -1..2
 };
 
-__device__ __forceinline__ double bspline3(double t) {
-  t = fabs(t);
-  if (t < 1.0) return 2.0 / 3.0 - t * t + 0.5 * t * t * t;
-  if (t < 2.0) {
-    double q = 2.0 - t;
-    return q * q * q / 6.0;
-  }
-  return 0.0;
-}
-
-// tap k (index 0..23 <-> k = -11..12) of the cardinal cubic spline kernel at fraction `frac`
-__device__ __forceinline__ float cardinal_tap(int ti, double frac) {
-  const double z1 = -0.26794919243112270647;  // sqrt(3) - 2
-  const double c0 = -6.0 * z1 / (1.0 - z1 * z1);
-  if (frac == 0.0) return ti == AP_R ? 1.f : 0.f;  // integer shift: exact delta
-  int k = ti - AP_R;
-  double h = 0.0;
-  for (int jq = -1; jq <= 2; ++jq) {
-    int e = k - jq;
-    if (e < 0) e = -e;
-    double zp = 1.0;
-    for (int q = 0; q < e; ++q) zp *= z1;
-    h += bspline3(frac - (double)jq) * c0 * zp;
-  }
-  return (float)h;
-}
-
-__device__ __forceinline__ AxisParams axis_params(double d, int n, double& frac) {
+__device__ __forceinline__ AxisParams axis_params(double d, int n) {
   AxisParams a;
   double nf = floor(-d);
-  frac = -d - nf;
-  a.sh = (int)nf;
-  // i - d >= 0  <=> i >= d ; i - d <= n-1 <=> i <= n-1+d
-  double lo = ceil(d), hi = floor((double)(n - 1) + d);
+  double frac = -d - nf;
+  // |d| beyond the int range: every output is outside; any in-range sh will do
+  a.sh = nf > 1.0e9 ? 1000000000 : (nf < -1.0e9 ? -1000000000 : (int)nf);
+  a.whole = frac == 0.0;
+  double lo = ceil(d), hi = floor((double)(n - 1) + d);   // i - d >= 0 ; i - d <= n - 1
   a.lo = lo < 0.0 ? 0 : (lo > (double)n ? n : (int)lo);
   a.hi = hi > (double)(n - 1) ? n - 1 : (hi < -1.0 ? -1 : (int)hi);
+  // cubic B-spline weights beta3(frac - j), j = -1..2, times c0 = -6 z1 / (1 - z1^2) = sqrt(3)
+  const float c0 = 1.7320508075688772f / 6.0f;
+  float f = (float)frac, g = 1.0f - f;
+  a.w[0] = c0 * (g * g * g);
+  a.w[1] = c0 * (4.0f - 6.0f * f * f + 3.0f * f * f * f);
+  a.w[2] = c0 * (4.0f - 6.0f * g * g + 3.0f * g * g * g);
+  a.w[3] = c0 * (f * f * f);
   return a;
 }
 
+// NOUT outputs from NOUT + 2*AP_R + 3 consecutive samples s[0..]: s[AP_R + 1 + k] is the sample
+// under output k (i0 of output k), coefficients k-1 .. k+2 are needed for output k.
+template <int NOUT>
+__device__ __forceinline__ void spline_run(const float* s, const float (&w)[4], float* out) {
+  constexpr int NC = NOUT + 3;           // coefficients q = -1 .. NOUT+1
+  float cp[NC], cm[NC];
+  // causal start at q = -1: sample index of q is AP_R + 1 + q
+  {
+    float a = s[0];                       // oldest tap, Horner from the far end
+#pragma unroll
+    for (int m = 1; m <= AP_R; ++m) a = fmaf(a, AP_Z1, s[m]);
+    cp[0] = a;                            // = sum_{m=0..R} z^m s[AP_R - m]
+  }
+#pragma unroll
+  for (int q = 1; q < NC; ++q) cp[q] = fmaf(cp[q - 1], AP_Z1, s[AP_R + q]);
+  {
+    float a = s[NC - 1 + 2 * AP_R];
+#pragma unroll
+    for (int m = 1; m <= AP_R; ++m) a = fmaf(a, AP_Z1, s[NC - 1 + 2 * AP_R - m]);
+    cm[NC - 1] = a;                       // = sum_{m=0..R} z^m s[AP_R + NC - 1 + m]
+  }
+#pragma unroll
+  for (int q = NC - 2; q >= 0; --q) cm[q] = fmaf(cm[q + 1], AP_Z1, s[AP_R + q]);
+#pragma unroll
+  for (int q = 0; q < NC; ++q) cp[q] = (cp[q] + cm[q]) - s[AP_R + q];   // coefficient / c0
+#pragma unroll
+  for (int k = 0; k < NOUT; ++k)
+    out[k] = fmaf(w[0], cp[k], fmaf(w[1], cp[k + 1], fmaf(w[2], cp[k + 2], w[3] * cp[k + 3])));
+}
+
+template <int TY>
 __global__ __launch_bounds__(256) void apply_shift_kernel(const uint16_t* __restrict__ in,
                                                           uint16_t* __restrict__ out, long long planes_per_frame,
-                                                          int Y, int X, const double* __restrict__ shifts) {
-  __shared__ float tile[AP_H][AP_W + 1];
-  __shared__ float rowp[AP_H][AP_TX + 1];
-  __shared__ float tapy[AP_TAPS], tapx[AP_TAPS];
+                                                          int Y, int X, const double* __restrict__ shifts,
+                                                          int vec_ok, int ntx) {
+  constexpr int TH = TY + 2 * AP_R + 3;        // staged rows
+  constexpr int YG = TY / 4;                   // outputs per thread in the y pass (4 row groups x 64 columns)
+  constexpr int NVEC = TH * (AP_TW / 8);       // 16-byte vectors per staged tile
+  constexpr int NV = (NVEC + 255) / 256;       // ... per thread
+  __shared__ float tile[TH * AP_PITCH];        // input tile; reused as the u32 output tile
+  __shared__ float rowp[TH * AP_RP];           // after the x pass
   __shared__ AxisParams pay, pax;
   const int tid = threadIdx.x;
   const long long plane = blockIdx.z;
   const long long frame = plane / planes_per_frame;
-  const double dy = shifts[2 * frame], dx = shifts[2 * frame + 1];
-  if (tid < 2 * AP_TAPS) {
-    bool isy = tid < AP_TAPS;
-    double frac;
-    AxisParams a = axis_params(isy ? dy : dx, isy ? Y : X, frac);
-    float h = cardinal_tap(isy ? tid : tid - AP_TAPS, frac);
-    if (isy) tapy[tid] = h;
-    else tapx[tid - AP_TAPS] = h;
+  if (tid < 2) {
+    AxisParams a = axis_params(shifts[2 * frame + tid], tid == 0 ? Y : X);
     if (tid == 0) pay = a;
-    if (tid == AP_TAPS) pax = a;
+    else pax = a;
   }
   __syncthreads();
-  const int ox = blockIdx.x * AP_TX, oy = blockIdx.y * AP_TY;
-  const uint16_t* p = in + (size_t)plane * Y * X;
-  uint16_t* po = out + (size_t)plane * Y * X;
   const AxisParams ay = pay, ax = pax;
-  // whole tile outside the valid range -> zeros
-  // stage the source tile (mirror boundary = the spline prefilter's boundary condition)
-  for (int i = tid; i < AP_H * AP_W; i += 256) {
-    int r = i / AP_W, c = i - r * AP_W;
-    int yy = reflect101_idx(oy + r + ay.sh - AP_R, Y);
-    int xx = reflect101_idx(ox + c + ax.sh - AP_R, X);
-    tile[r][c] = (float)p[(size_t)yy * X + xx];
+  const int oy = blockIdx.y * TY;
+  const uint16_t* __restrict__ p = in + (size_t)plane * Y * X;
+  uint16_t* __restrict__ po = out + (size_t)plane * Y * X;
+  const int yend = min(oy + TY, Y);
+  const int tiles_x = (X + AP_TX - 1) / AP_TX;
+  const int tx0 = blockIdx.x * ntx, tx1 = min(tx0 + ntx, tiles_x);
+  const bool rows_valid = !(oy > ay.hi || yend - 1 < ay.lo);
+  const int row0 = oy + ay.sh - 1 - AP_R;
+
+  // this thread's staged vectors: (row, vector) are the same for every tile of the run
+  size_t voff[NV];
+  int lds_off[NV];
+#pragma unroll
+  for (int jv = 0; jv < NV; ++jv) {
+    int i = min(tid + jv * 256, NVEC - 1);       // clamped, so every load is unconditional
+    int r = i / (AP_TW / 8), v = i - r * (AP_TW / 8);
+    int yy = row0 + r;
+    if (yy < 0 || yy >= Y) yy = rows_valid ? reflect101_idx(yy, Y) : 0;
+    voff[jv] = (size_t)yy * X + 8 * v;
+    lds_off[jv] = r * AP_PITCH + 8 * v;
   }
-  __syncthreads();
-  // x pass: AP_H rows x AP_TX outputs; each thread 8 consecutive outputs of one row
-  for (int i = tid; i < AP_H * (AP_TX / 8); i += 256) {
-    int r = i / (AP_TX / 8), c0 = (i - r * (AP_TX / 8)) * 8;
-    float acc[8];
+  u16x8 q[NV];
+  auto geom = [&](int tx, int& a0, int& o, bool& fast, bool& valid) {
+    const int ox = tx * AP_TX;
+    const int first = ox + ax.sh - 1 - AP_R;
+    a0 = first & ~7;                             // arithmetic: rounds toward -inf for negatives too
+    o = first - a0;
+    valid = rows_valid && !(ox > ax.hi || min(ox + AP_TX, X) - 1 < ax.lo);
+    fast = valid && vec_ok && a0 >= 0 && a0 + AP_TW <= X;
+  };
+  auto preload = [&](int a0) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
-    float win[8 + AP_TAPS - 1];
-#pragma unroll
-    for (int q = 0; q < 8 + AP_TAPS - 1; ++q) win[q] = tile[r][c0 + q];
-#pragma unroll
-    for (int k = 0; k < AP_TAPS; ++k) {
-      float t = tapx[k];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) acc[q] = fmaf(t, win[q + k], acc[q]);
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) rowp[r][c0 + q] = acc[q];
-  }
-  __syncthreads();
-  // y pass: each thread one column, 16 consecutive output rows
+    for (int jv = 0; jv < NV; ++jv) q[jv] = load8(p + voff[jv] + a0);
+  };
   {
-    const int c = tid & 63, r0 = (tid >> 6) * 16;
-    float acc[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    float win[16 + AP_TAPS - 1];
-#pragma unroll
-    for (int q = 0; q < 16 + AP_TAPS - 1; ++q) win[q] = rowp[r0 + q][c];
-#pragma unroll
-    for (int k = 0; k < AP_TAPS; ++k) {
-      float t = tapy[k];
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[q] = fmaf(t, win[q + k], acc[q]);
+    int a0, o;
+    bool fast, valid;
+    geom(tx0, a0, o, fast, valid);
+    if (fast) preload(a0);
+  }
+
+  for (int tx = tx0; tx < tx1; ++tx) {
+    const int ox = tx * AP_TX;
+    int a0, o;
+    bool fast, valid;
+    geom(tx, a0, o, fast, valid);
+    int na0 = 0, no = 0;
+    bool nfast = false, nvalid = false;
+    if (tx + 1 < tx1) geom(tx + 1, na0, no, nfast, nvalid);
+
+    if (!valid) {  // no output of this tile has its source inside the image: zeros
+      for (int i = tid; i < TY * AP_TX; i += 256) {
+        int r = i / AP_TX, c = i - r * AP_TX;
+        if (oy + r < Y && ox + c < X) po[(size_t)(oy + r) * X + ox + c] = 0;
+      }
+      if (nfast) preload(na0);
+      continue;
     }
-    const int xx = ox + c;
-    if (xx < X) {
-      const bool xin = xx >= ax.lo && xx <= ax.hi;
+
+    // ---- stage the source tile as float
+    if (fast) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        int yy = oy + r0 + q;
-        if (yy < Y) {
-          float v = acc[q];
-          bool inside = xin && yy >= ay.lo && yy <= ay.hi;
-          v = inside ? fminf(fmaxf(v, 0.f), 65535.f) : 0.f;
-          po[(size_t)yy * X + xx] = (uint16_t)v;  // truncation toward zero
+      for (int jv = 0; jv < NV; ++jv) {
+        if (tid + jv * 256 < NVEC) {
+          float* t = tile + lds_off[jv];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) t[k] = (float)q[jv].v[k];
         }
       }
+    } else {  // image border (or unaligned pitch): mirrored scalar loads
+      for (int i = tid; i < TH * AP_TW; i += 256) {
+        int r = i / AP_TW, c = i - r * AP_TW;
+        int yy = reflect101_idx(row0 + r, Y);
+        int xx = reflect101_idx(a0 + c, X);
+        tile[r * AP_PITCH + c] = (float)p[(size_t)yy * X + xx];
+      }
     }
+    __syncthreads();
+    if (nfast) preload(na0);   // next tile's loads fly while this one is filtered
+
+    // ---- x pass: TH rows x 8 groups of 8 outputs; lanes run along rows (bank-conflict free)
+    for (int i = tid; i < TH * 8; i += 256) {
+      int m = i / TH, r = i - m * TH;
+      const float* t = tile + r * AP_PITCH + o + 8 * m;
+      float res[8];
+      if (ax.whole) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) res[k] = t[AP_R + 1 + k];
+      } else {
+        float s[8 + 2 * AP_R + 3];
+#pragma unroll
+        for (int k = 0; k < 8 + 2 * AP_R + 3; ++k) s[k] = t[k];
+        spline_run<8>(s, ax.w, res);
+      }
+      float* d = rowp + r * AP_RP + 8 * m;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) d[k] = res[k];
+    }
+    __syncthreads();
+
+    // ---- y pass: one column per lane, YG consecutive rows per thread; results -> u32 tile in LDS
+    unsigned* otile = reinterpret_cast<unsigned*>(tile);
+    {
+      const int c = tid & 63, y0 = (tid >> 6) * YG;
+      const float* t = rowp + y0 * AP_RP + c;
+      float res[YG];
+      if (ay.whole) {
+#pragma unroll
+        for (int k = 0; k < YG; ++k) res[k] = t[(AP_R + 1 + k) * AP_RP];
+      } else {
+        float s[YG + 2 * AP_R + 3];
+#pragma unroll
+        for (int k = 0; k < YG + 2 * AP_R + 3; ++k) s[k] = t[k * AP_RP];
+        spline_run<YG>(s, ay.w, res);
+      }
+      const int xx = ox + c;
+      const bool xin = xx >= ax.lo && xx <= ax.hi;
+#pragma unroll
+      for (int k = 0; k < YG; ++k) {
+        int yy = oy + y0 + k;
+        bool inside = xin && yy >= ay.lo && yy <= ay.hi;
+        float v = inside ? fminf(fmaxf(res[k], 0.f), 65535.f) : 0.f;
+        otile[(y0 + k) * AP_RP + c] = (unsigned)v;   // truncation toward zero
+      }
+    }
+    __syncthreads();
+
+    // ---- store: 16 bytes per lane when the row pitch allows it
+    if (vec_ok && ox + AP_TX <= X) {
+      for (int i = tid; i < TY * (AP_TX / 8); i += 256) {
+        int r = i / (AP_TX / 8), sgm = i - r * (AP_TX / 8);
+        if (oy + r < Y) {
+          const unsigned* sp = otile + r * AP_RP + 8 * sgm;
+          u16x8 w8;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) w8.v[k] = (uint16_t)sp[k];
+          store8(po + (size_t)(oy + r) * X + ox + 8 * sgm, w8);
+        }
+      }
+    } else {
+      for (int i = tid; i < TY * AP_TX; i += 256) {
+        int r = i / AP_TX, c = i - r * AP_TX;
+        if (oy + r < Y && ox + c < X) po[(size_t)(oy + r) * X + ox + c] = (uint16_t)otile[r * AP_RP + c];
+      }
+    }
+    __syncthreads();   // the output tile aliases the input tile of the next iteration
   }
 }
 
@@ -847,18 +956,22 @@ static int launch_mip(const uint16_t* in, long long in_stride, uint16_t* out, lo
 
 static int launch_apply(const uint16_t* in, uint16_t* out, long long n_frames, long long ppf, int Y, int X,
                         const double* shifts, hipStream_t st) {
-  long long planes = n_frames * ppf;
-  dim3 grid((X + AP_TX - 1) / AP_TX, (Y + AP_TY - 1) / AP_TY, 1);
+  constexpr int TY = 32;
+  const int vec_ok = (X % 8 == 0) && (((long long)Y * X) % 8 == 0) && aligned16(in) && aligned16(out);
+  const int tiles_x = (X + AP_TX - 1) / AP_TX;
+  // each workgroup walks `ntx` tiles along x, prefetching the next tile while it filters this one
+  int ntx = 8;
+  while (ntx > 1 && (long long)((tiles_x + ntx - 1) / ntx) * ((Y + TY - 1) / TY) * ppf * n_frames < 8192) ntx >>= 1;
+  dim3 grid((tiles_x + ntx - 1) / ntx, (Y + TY - 1) / TY, 1);
   // blockIdx.z is limited to 65535: chunk by whole frames
   long long fpc = 65535 / ppf;
   if (fpc < 1) return IAP_E_UNSUPPORTED;
   for (long long f0 = 0; f0 < n_frames; f0 += fpc) {
     long long nf = n_frames - f0 < fpc ? n_frames - f0 : fpc;
     grid.z = (unsigned)(nf * ppf);
-    { ProfScope ps_(K_APPLY, st); hipLaunchKernelGGL(apply_shift_kernel, grid, dim3(256), 0, st, in + (size_t)f0 * ppf * Y * X,
-                       out + (size_t)f0 * ppf * Y * X, ppf, Y, X, shifts + 2 * f0); }
+    { ProfScope ps_(K_APPLY, st); hipLaunchKernelGGL(apply_shift_kernel<TY>, grid, dim3(256), 0, st, in + (size_t)f0 * ppf * Y * X,
+                       out + (size_t)f0 * ppf * Y * X, ppf, Y, X, shifts + 2 * f0, vec_ok, ntx); }
   }
-  (void)planes;
   IAP_LAUNCH_CHECK();
   return IAP_OK;
 }
