@@ -34,37 +34,51 @@ struct f4 {
   float v[4];
 };
 
-template <typename T>
-__device__ __forceinline__ f4 load_row4(const T* __restrict__ row, int x, bool ok);
+// raw (unconverted) row segment of one lane: 4 pixels
+template <typename T> struct Raw4;
+template <> struct Raw4<uint16_t> { uint2 w; };
+template <> struct Raw4<float> { float4 w; };
 
+template <typename T>
+__device__ __forceinline__ Raw4<T> load_raw4(const T* __restrict__ row, int x, bool ok);
 template <>
-__device__ __forceinline__ f4 load_row4<uint16_t>(const uint16_t* __restrict__ row, int x, bool ok) {
-  f4 r;
-  if (ok) {
-    uint2 w = *reinterpret_cast<const uint2*>(row + x);
-    r.v[0] = (float)(w.x & 0xffffu);
-    r.v[1] = (float)(w.x >> 16);
-    r.v[2] = (float)(w.y & 0xffffu);
-    r.v[3] = (float)(w.y >> 16);
-  } else {
-    r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0.f;
-  }
+__device__ __forceinline__ Raw4<uint16_t> load_raw4<uint16_t>(const uint16_t* __restrict__ row, int x, bool ok) {
+  Raw4<uint16_t> r;
+  r.w = ok ? *reinterpret_cast<const uint2*>(row + x) : make_uint2(0u, 0u);
   return r;
 }
-
 template <>
-__device__ __forceinline__ f4 load_row4<float>(const float* __restrict__ row, int x, bool ok) {
-  f4 r;
-  if (ok) {
-    float4 w = *reinterpret_cast<const float4*>(row + x);
-    r.v[0] = w.x;
-    r.v[1] = w.y;
-    r.v[2] = w.z;
-    r.v[3] = w.w;
-  } else {
-    r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0.f;
-  }
+__device__ __forceinline__ Raw4<float> load_raw4<float>(const float* __restrict__ row, int x, bool ok) {
+  Raw4<float> r;
+  r.w = ok ? *reinterpret_cast<const float4*>(row + x) : make_float4(0.f, 0.f, 0.f, 0.f);
   return r;
+}
+__device__ __forceinline__ f4 to_f4(const Raw4<uint16_t>& r) {
+  f4 o;
+  o.v[0] = (float)(r.w.x & 0xffffu);
+  o.v[1] = (float)(r.w.x >> 16);
+  o.v[2] = (float)(r.w.y & 0xffffu);
+  o.v[3] = (float)(r.w.y >> 16);
+  return o;
+}
+__device__ __forceinline__ f4 to_f4(const Raw4<float>& r) {
+  f4 o;
+  o.v[0] = r.w.x; o.v[1] = r.w.y; o.v[2] = r.w.z; o.v[3] = r.w.w;
+  return o;
+}
+__device__ __forceinline__ uint2 as_u2(const Raw4<uint16_t>& r) { return r.w; }
+__device__ __forceinline__ uint2 as_u2(const Raw4<float>&) { return make_uint2(0u, 0u); }
+template <typename T>
+__device__ __forceinline__ f4 load_row4(const T* __restrict__ row, int x, bool ok) {
+  return to_f4(load_raw4<T>(row, x, ok));
+}
+
+// value of lane-1 / lane+1 through DPP wave shifts (one VALU move each, no LDS traffic)
+__device__ __forceinline__ float from_left(float x) {   // lane i receives lane i-1
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x138, 0xf, 0xf, false));  // wave_shr:1
+}
+__device__ __forceinline__ float from_right(float x) {  // lane i receives lane i+1
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x130, 0xf, 0xf, false));  // wave_shl:1
 }
 
 struct SmoGeom {
@@ -73,36 +87,51 @@ struct SmoGeom {
   int tasks_per_plane;  // nstrips * nbands rounded up to a multiple of SMO_WAVES
 };
 
+// Per-lane constants of the marching kernel's inner step.
+struct SmoLane {
+  bool edge_l, edge_r;  // this lane holds image column 0 (as its col 0) / X-1 (as its col 3)
+  bool mir_l, mir_r;    // lane 1 of the leftmost / lane 62 of the rightmost strip: mirrored halo
+  bool edge_strip;      // wave-uniform: leftmost or rightmost strip
+};
+
 // One row of horizontally 7-summed unit-gradient components from image rows v-1, v, v+1.
-__device__ __forceinline__ void smo_row(const f4& A, const f4& B, const f4& Cn, int v, int Y, int X, int xl,
-                                        int lane, bool left_strip, bool right_strip, f4& hy, f4& hx) {
-  float bl = __shfl_up(B.v[3], 1, 64);
-  float br = __shfl_down(B.v[0], 1, 64);
+// first_row / last_row (wave-uniform): np.gradient's one-sided differences at the plane edge.
+__device__ __forceinline__ void smo_row(const f4& A, const f4& B, const f4& Cn, bool first_row, bool last_row,
+                                        const SmoLane& ln, f4& hy, f4& hx) {
+  const float bl = from_left(B.v[3]);
+  const float br = from_right(B.v[0]);
+  const float ys = (first_row || last_row) ? 1.0f : 0.5f;
   float ny[4], nx[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    float gy = (v == 0) ? (Cn.v[i] - B.v[i]) : (v == Y - 1) ? (B.v[i] - A.v[i]) : 0.5f * (Cn.v[i] - A.v[i]);
+    const float up = first_row ? B.v[i] : A.v[i];
+    const float dn = last_row ? B.v[i] : Cn.v[i];
+    const float gy = ys * (dn - up);
     float l = (i == 0) ? bl : B.v[i - 1];
     float r = (i == 3) ? br : B.v[i + 1];
-    int x = xl + i;
-    float gx = (x == 0) ? (r - B.v[i]) : (x == X - 1) ? (B.v[i] - l) : 0.5f * (r - l);
-    float n2 = gy * gy + gx * gx;
-    float inv = n2 > 0.f ? rsqrtf(n2) : 0.f;
+    float xs = 0.5f;
+    if (i == 0 && ln.edge_l) { l = B.v[0]; xs = 1.0f; }
+    if (i == 3 && ln.edge_r) { r = B.v[3]; xs = 1.0f; }
+    const float gx = xs * (r - l);
+    const float n2 = gy * gy + gx * gx;
+    const float inv = n2 > 0.f ? __builtin_amdgcn_rsqf(n2) : 0.f;
     ny[i] = gy * inv;
     nx[i] = gx * inv;
   }
   // neighbours' columns: left lane's cols 1..3, right lane's cols 0..2
-  float ly1 = __shfl_up(ny[1], 1, 64), ly2 = __shfl_up(ny[2], 1, 64), ly3 = __shfl_up(ny[3], 1, 64);
-  float lx1 = __shfl_up(nx[1], 1, 64), lx2 = __shfl_up(nx[2], 1, 64), lx3 = __shfl_up(nx[3], 1, 64);
-  float ry0 = __shfl_down(ny[0], 1, 64), ry1 = __shfl_down(ny[1], 1, 64), ry2 = __shfl_down(ny[2], 1, 64);
-  float rx0 = __shfl_down(nx[0], 1, 64), rx1 = __shfl_down(nx[1], 1, 64), rx2 = __shfl_down(nx[2], 1, 64);
-  if (left_strip && lane == 1) {  // columns -3,-2,-1 mirror columns 2,1,0 (scipy 'reflect')
-    ly1 = ny[2]; ly2 = ny[1]; ly3 = ny[0];
-    lx1 = nx[2]; lx2 = nx[1]; lx3 = nx[0];
-  }
-  if (right_strip && lane == 62) {  // columns X,X+1,X+2 mirror X-1,X-2,X-3
-    ry0 = ny[3]; ry1 = ny[2]; ry2 = ny[1];
-    rx0 = nx[3]; rx1 = nx[2]; rx2 = nx[1];
+  float ly1 = from_left(ny[1]), ly2 = from_left(ny[2]), ly3 = from_left(ny[3]);
+  float lx1 = from_left(nx[1]), lx2 = from_left(nx[2]), lx3 = from_left(nx[3]);
+  float ry0 = from_right(ny[0]), ry1 = from_right(ny[1]), ry2 = from_right(ny[2]);
+  float rx0 = from_right(nx[0]), rx1 = from_right(nx[1]), rx2 = from_right(nx[2]);
+  if (ln.edge_strip) {  // wave-uniform: only the first and the last strip of a row mirror a halo
+    if (ln.mir_l) {  // columns -3,-2,-1 mirror columns 2,1,0 (scipy 'reflect')
+      ly1 = ny[2]; ly2 = ny[1]; ly3 = ny[0];
+      lx1 = nx[2]; lx2 = nx[1]; lx3 = nx[0];
+    }
+    if (ln.mir_r) {  // columns X,X+1,X+2 mirror X-1,X-2,X-3
+      ry0 = ny[3]; ry1 = ny[2]; ry2 = ny[1];
+      rx0 = nx[3]; rx1 = nx[2]; rx2 = nx[1];
+    }
   }
   float sy = (ny[0] + ny[1]) + (ny[2] + ny[3]);
   float sx = (nx[0] + nx[1]) + (nx[2] + nx[3]);
@@ -163,13 +192,31 @@ __global__ __launch_bounds__(SMO_WAVES * 64) void smo_march_kernel(
   }
 
   float ry[7][4], rx[7][4];  // vertical ring, statically indexed
+  float vy[4], vx[4];        // running vertical 7-row sums (re-summed exactly every 7th row)
   const int vbase = y0 - 3;
   const int vfirst = top ? 0 : vbase;
-  // rows v-1, v, v+1 of the row being computed, plus v+2 already in flight
+  SmoLane ln;
+  ln.edge_l = xl == 0;
+  ln.edge_r = xl + 3 == X - 1;
+  ln.mir_l = left_strip && lane == 1;
+  ln.mir_r = right_strip && lane == 62;
+  ln.edge_strip = left_strip || right_strip;
+  // rows v-1, v, v+1 of the row being computed; rows v+2 and v+3 are in flight, unconverted
   f4 A = load_row4<T>(p + (size_t)max(vfirst - 1, 0) * X, xl, col_ok);
   f4 B = load_row4<T>(p + (size_t)vfirst * X, xl, col_ok);
   f4 Cn = load_row4<T>(p + (size_t)min(vfirst + 1, Y - 1) * X, xl, col_ok);
-  f4 Dn = load_row4<T>(p + (size_t)min(vfirst + 2, Y - 1) * X, xl, col_ok);
+  Raw4<T> Dn = load_raw4<T>(p + (size_t)min(vfirst + 2, Y - 1) * X, xl, col_ok);
+  Raw4<T> En = load_raw4<T>(p + (size_t)min(vfirst + 3, Y - 1) * X, xl, col_ok);
+  // u16 source == histogram source: the unconverted rows are kept in a 7-slot ring (same slot
+  // numbering as ry/rx) so that emit() never re-reads the image
+  constexpr bool RAWRING = (MODE == SMO_MODE_HIST) && sizeof(T) == 2;
+  uint2 rawr[7];
+#pragma unroll
+  for (int q = 0; q < 7; ++q) rawr[q] = make_uint2(0u, 0u);
+  if (RAWRING && top) {  // rows 0 and 1 live in slots 3 and 4
+    rawr[3] = as_u2(load_raw4<T>(p, xl, col_ok));
+    rawr[4] = as_u2(load_raw4<T>(p + (size_t)X, xl, col_ok));
+  }
 
   // Put virtual row v into ring slot PH (PH is a compile-time constant after unrolling).
   // Rows Y, Y+1, Y+2 mirror Y-1, Y-2, Y-3, i.e. the slots filled 1, 3 and 5 steps ago.
@@ -177,11 +224,13 @@ __global__ __launch_bounds__(SMO_WAVES * 64) void smo_march_kernel(
   do {                                                                                               \
     if ((VROW) < Y) {                                                                                   \
       f4 hy_, hx_;                                                                                   \
-      smo_row(A, B, Cn, (VROW), Y, X, xl, lane, left_strip, right_strip, hy_, hx_);                     \
+      smo_row(A, B, Cn, (VROW) == 0, (VROW) == Y - 1, ln, hy_, hx_);                                    \
       A = B;                                                                                         \
       B = Cn;                                                                                        \
-      Cn = Dn;                                                                                       \
-      Dn = load_row4<T>(p + (size_t)min((VROW) + 3, Y - 1) * X, xl, col_ok);                            \
+      Cn = to_f4(Dn);                                                                                \
+      if (RAWRING) rawr[((PH) + 2) % 7] = as_u2(Dn);                      \
+      Dn = En;                                                                                       \
+      En = load_raw4<T>(p + (size_t)min((VROW) + 4, Y - 1) * X, xl, col_ok);                            \
       _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
         ry[PH][i] = hy_.v[i];                                                                        \
         rx[PH][i] = hx_.v[i];                                                                        \
@@ -196,6 +245,12 @@ __global__ __launch_bounds__(SMO_WAVES * 64) void smo_march_kernel(
       }                                                                                              \
     }                                                                                                \
   } while (0)
+
+#define SMO_RESUM()                                                                                    \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
+    vy[i] = ((ry[0][i] + ry[1][i]) + (ry[2][i] + ry[3][i])) + ((ry[4][i] + ry[5][i]) + ry[6][i]);      \
+    vx[i] = ((rx[0][i] + rx[1][i]) + (rx[2][i] + rx[3][i])) + ((rx[4][i] + rx[5][i]) + rx[6][i]);      \
+  }
 
   // ---- prologue: fill the ring with virtual rows vbase .. vbase+6
 #pragma unroll
@@ -215,15 +270,10 @@ __global__ __launch_bounds__(SMO_WAVES * 64) void smo_march_kernel(
       ry[2][i] = ry[3][i]; rx[2][i] = rx[3][i];
     }
   }
+  SMO_RESUM();
 
-  auto emit = [&](int oy) {
-    float vy[4], vx[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      vy[i] = ((ry[0][i] + ry[1][i]) + (ry[2][i] + ry[3][i])) + ((ry[4][i] + ry[5][i]) + ry[6][i]);
-      vx[i] = ((rx[0][i] + rx[1][i]) + (rx[2][i] + rx[3][i])) + ((rx[4][i] + rx[5][i]) + rx[6][i]);
-    }
-    const bool lane_own = lane >= 1 && lane <= 62 && xl >= own_lo && xl < own_hi;
+  const bool lane_own = lane >= 1 && lane <= 62 && xl >= own_lo && xl < own_hi;
+  auto emit = [&](int oy, const uint2& rawrow) {
     if (MODE == SMO_MODE_IMAGE) {
       if (lane_own) {
         float4 o;
@@ -234,18 +284,23 @@ __global__ __launch_bounds__(SMO_WAVES * 64) void smo_march_kernel(
         *reinterpret_cast<float4*>(smo_out + ((size_t)plane * Y + oy) * X + xl) = o;
       }
     } else {
-      if (lane_own) {
-        uint2 w = *reinterpret_cast<const uint2*>(po + (size_t)oy * X + xl);
+      bool bgp[4];
+      bool any = false;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bgp[i] = lane_own && (vy[i] * vy[i] + vx[i] * vx[i] < thr2);
+        any |= bgp[i];
+      }
+      if (any) {  // ~5 % of the background pixels pass: most lanes skip the whole block
+        uint2 w = RAWRING ? rawrow : *reinterpret_cast<const uint2*>(po + (size_t)oy * X + xl);
         unsigned px[4] = {w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          float s2 = vy[i] * vy[i] + vx[i] * vx[i];
-          if (s2 < thr2) {
+          if (bgp[i]) {
             unsigned val = px[i];
             unsigned rel = val - win_base;
             if (rel < (unsigned)SMO_WIN) {
               atomicAdd(&lds_fine[wave][rel], 1u);
-              atomicAdd(&lds_coarse[wave][val >> 8], 1u);
             } else {
               atomicAdd(hfine + val, 1u);
               atomicAdd(hcoarse + (val >> 8), 1u);
@@ -256,25 +311,74 @@ __global__ __launch_bounds__(SMO_WAVES * 64) void smo_march_kernel(
     }
   };
 
-  emit(y0);
-  // ---- march: output row oy needs virtual row oy+3, which goes into ring slot ph
+  emit(y0, rawr[3]);
+  // ---- march: output row oy needs virtual row oy+3, which goes into ring slot ph.
+  // SMO_STEP(ph, FILL): replace slot ph, update the running sums, emit.
+#define SMO_STEP(PH, FILLER)                                                                           \
+  do {                                                                                               \
+    float oy_[4], ox_[4];                                                                            \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
+      oy_[i] = ry[PH][i];                                                                            \
+      ox_[i] = rx[PH][i];                                                                            \
+    }                                                                                                \
+    FILLER(PH, oy + 3);                                                                              \
+    if ((PH) == 0) {                                                                                 \
+      SMO_RESUM();                                                                                   \
+    } else {                                                                                         \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
+        vy[i] += ry[PH][i] - oy_[i];                                                                 \
+        vx[i] += rx[PH][i] - ox_[i];                                                                 \
+      }                                                                                              \
+    }                                                                                                \
+    emit(oy, rawr[((PH) + 4) % 7]);                                                                  \
+    ++oy;                                                                                            \
+  } while (0)
+  // interior rows: no per-row conditions, so the 7x unrolled body is straight-line code
+#define SMO_FILL_FAST(PH, VROW)                                                                       \
+  do {                                                                                               \
+    f4 hy_, hx_;                                                                                     \
+    smo_row(A, B, Cn, false, false, ln, hy_, hx_);                                                   \
+    A = B;                                                                                           \
+    B = Cn;                                                                                          \
+    Cn = to_f4(Dn);                                                                                  \
+    if (RAWRING) rawr[((PH) + 2) % 7] = as_u2(Dn);                        \
+    Dn = En;                                                                                         \
+    En = load_raw4<T>(p + (size_t)((VROW) + 4) * X, xl, col_ok);                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
+      ry[PH][i] = hy_.v[i];                                                                          \
+      rx[PH][i] = hx_.v[i];                                                                          \
+    }                                                                                                \
+  } while (0)
+
   int oy = y0 + 1;
+  // fast groups need rows oy+3 .. oy+9 strictly inside the plane and the prefetch row oy+13 <= Y-1
+  while (oy + 7 <= yend && oy + 13 < Y && oy + 3 > 0) {
+    SMO_STEP(0, SMO_FILL_FAST);
+    SMO_STEP(1, SMO_FILL_FAST);
+    SMO_STEP(2, SMO_FILL_FAST);
+    SMO_STEP(3, SMO_FILL_FAST);
+    SMO_STEP(4, SMO_FILL_FAST);
+    SMO_STEP(5, SMO_FILL_FAST);
+    SMO_STEP(6, SMO_FILL_FAST);
+  }
   while (oy < yend) {
 #pragma unroll
     for (int ph = 0; ph < 7; ++ph) {
-      if (oy < yend) {
-        SMO_FILL(ph, oy + 3);
-        emit(oy);
-        ++oy;
-      }
+      if (oy < yend) SMO_STEP(ph, SMO_FILL);
     }
   }
+#undef SMO_STEP
+#undef SMO_FILL_FAST
 #undef SMO_FILL
+#undef SMO_RESUM
 
-  if (MODE == SMO_MODE_HIST) {  // flush this wave's private histogram
+  if (MODE == SMO_MODE_HIST) {  // flush this wave's private histogram (+ its coarse 256-bin view)
     for (int i = lane; i < SMO_WIN; i += 64) {
       unsigned c = lds_fine[wave][i];
-      if (c) atomicAdd(hfine + win_base + i, c);
+      if (c) {
+        atomicAdd(hfine + win_base + i, c);
+        atomicAdd(&lds_coarse[wave][(win_base + i) >> 8], c);
+      }
     }
     for (int i = lane; i < HIST_COARSE; i += 64) {
       unsigned c = lds_coarse[wave][i];

@@ -17,6 +17,7 @@
 // tiles; mirror boundary, zero outside, clip, truncate to u16.  Integer shifts degenerate to
 // a delta kernel and are therefore exact copies.
 #include <math.h>
+#include <stdlib.h>
 #include "common.h"
 
 namespace iap {
@@ -597,12 +598,16 @@ __global__ __launch_bounds__(256) void apply_shift_kernel(const uint16_t* __rest
   }
   __syncthreads();
   const AxisParams ay = pay, ax = pax;
-  const int oy = blockIdx.y * TY;
+  // XCD-aware placement: every XCD (blocks b, b+8, ... share one) gets a contiguous band of
+  // rows, so the halo rows two vertically adjacent workgroups both read are served by one L2
+  const unsigned lin = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  const unsigned bxi = lin % gridDim.x, byi = lin / gridDim.x;
+  const int oy = byi * TY;
   const uint16_t* __restrict__ p = in + (size_t)plane * Y * X;
   uint16_t* __restrict__ po = out + (size_t)plane * Y * X;
   const int yend = min(oy + TY, Y);
   const int tiles_x = (X + AP_TX - 1) / AP_TX;
-  const int tx0 = blockIdx.x * ntx, tx1 = min(tx0 + ntx, tiles_x);
+  const int tx0 = bxi * ntx, tx1 = min(tx0 + ntx, tiles_x);
   const bool rows_valid = !(oy > ay.hi || yend - 1 < ay.lo);
   const int row0 = oy + ay.sh - 1 - AP_R;
 
@@ -956,11 +961,13 @@ static int launch_mip(const uint16_t* in, long long in_stride, uint16_t* out, lo
 
 static int launch_apply(const uint16_t* in, uint16_t* out, long long n_frames, long long ppf, int Y, int X,
                         const double* shifts, hipStream_t st) {
-  constexpr int TY = 32;
+  int TY = 32;
+  if (const char* e = getenv("IAP_APPLY_TY")) TY = atoi(e) == 64 ? 64 : 32;
   const int vec_ok = (X % 8 == 0) && (((long long)Y * X) % 8 == 0) && aligned16(in) && aligned16(out);
   const int tiles_x = (X + AP_TX - 1) / AP_TX;
   // each workgroup walks `ntx` tiles along x, prefetching the next tile while it filters this one
-  int ntx = 8;
+  int ntx = 16;
+  if (const char* e = getenv("IAP_APPLY_NTX")) ntx = atoi(e) > 0 ? atoi(e) : ntx;
   while (ntx > 1 && (long long)((tiles_x + ntx - 1) / ntx) * ((Y + TY - 1) / TY) * ppf * n_frames < 8192) ntx >>= 1;
   dim3 grid((tiles_x + ntx - 1) / ntx, (Y + TY - 1) / TY, 1);
   // blockIdx.z is limited to 65535: chunk by whole frames
@@ -969,8 +976,13 @@ static int launch_apply(const uint16_t* in, uint16_t* out, long long n_frames, l
   for (long long f0 = 0; f0 < n_frames; f0 += fpc) {
     long long nf = n_frames - f0 < fpc ? n_frames - f0 : fpc;
     grid.z = (unsigned)(nf * ppf);
-    { ProfScope ps_(K_APPLY, st); hipLaunchKernelGGL(apply_shift_kernel<TY>, grid, dim3(256), 0, st, in + (size_t)f0 * ppf * Y * X,
-                       out + (size_t)f0 * ppf * Y * X, ppf, Y, X, shifts + 2 * f0, vec_ok, ntx); }
+    ProfScope ps_(K_APPLY, st);
+    if (TY == 64)
+      hipLaunchKernelGGL(apply_shift_kernel<64>, grid, dim3(256), 0, st, in + (size_t)f0 * ppf * Y * X,
+                         out + (size_t)f0 * ppf * Y * X, ppf, Y, X, shifts + 2 * f0, vec_ok, ntx);
+    else
+      hipLaunchKernelGGL(apply_shift_kernel<32>, grid, dim3(256), 0, st, in + (size_t)f0 * ppf * Y * X,
+                         out + (size_t)f0 * ppf * Y * X, ppf, Y, X, shifts + 2 * f0, vec_ok, ntx);
   }
   IAP_LAUNCH_CHECK();
   return IAP_OK;

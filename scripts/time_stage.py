@@ -22,3 +22,11 @@ for name, sh in (("zero", (0.0, 0.0)), ("int", (3.0, -5.0)), ("fracx", (0.0, 0.3
 y = torch.empty_like(x)
 ms = timeit(lambda: y.copy_(x))
 print(f"torch copy   {ms:8.3f} ms  {n * 2048 * 2048 * 4 / ms / 1e9:8.1f} GB/s")
+
+import numpy as np
+rng = np.random.default_rng(0)
+img = torch.from_numpy((rng.poisson(100, size=(8, 2048, 2048)) + 400).astype(np.int32)).to(dev).to(torch.uint16)
+img = img.repeat(n // 8, 1, 1).contiguous()
+out = torch.empty_like(img)
+ms = timeit(lambda: ops.bg_smo(img, 0.045, out=out))
+print(f"bg_smo       {ms:8.3f} ms  {ms / n * 1e3:7.2f} us/plane")
