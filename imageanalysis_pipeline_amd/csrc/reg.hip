@@ -88,11 +88,11 @@ __device__ __forceinline__ void dftR(cf* v) {
 }
 
 // One Stockham radix-R pass over an N-point sequence held in LDS (padded index), done by
-// N/8 threads (8 points each).  tw[k] = exp(-2 pi i k / N).  Ends with a barrier.
-template <int N, int R, int SIGN, int Ns>
+// N/E threads (E points each).  tw[k] = exp(-2 pi i k / N).  Ends with a barrier.
+template <int N, int E, int R, int SIGN, int Ns>
 __device__ __forceinline__ void fft_pass(cf* s, int j, const cf* __restrict__ tw) {
-  constexpr int NT = N / 8;
-  constexpr int NB = 8 / R;
+  constexpr int NT = N / E;
+  constexpr int NB = E / R;
   cf v[NB][R];
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
@@ -103,21 +103,12 @@ __device__ __forceinline__ void fft_pass(cf* s, int j, const cf* __restrict__ tw
       const int k = jj & (Ns - 1);
       cf w1 = tw[k * (N / (Ns * R))];
       if (SIGN > 0) w1.y = -w1.y;
-      if constexpr (R == 2) {
-        v[b][1] = cmul(v[b][1], w1);
-      } else {
-        cf w2 = cmul(w1, w1);
-        cf w3 = cmul(w2, w1);
-        v[b][1] = cmul(v[b][1], w1);
-        v[b][2] = cmul(v[b][2], w2);
-        v[b][3] = cmul(v[b][3], w3);
-        if constexpr (R == 8) {
-          cf w4 = cmul(w2, w2);
-          v[b][4] = cmul(v[b][4], w4);
-          v[b][5] = cmul(v[b][5], cmul(w4, w1));
-          v[b][6] = cmul(v[b][6], cmul(w4, w2));
-          v[b][7] = cmul(v[b][7], cmul(w4, w3));
-        }
+      // powers of w1 by a running product: two live twiddle registers instead of seven
+      cf w = w1;
+#pragma unroll
+      for (int r = 1; r < R; ++r) {
+        v[b][r] = cmul(v[b][r], w);
+        if (r + 1 < R) w = cmul(w, w1);
       }
     }
     dftR<R, SIGN>(v[b]);
@@ -133,20 +124,21 @@ __device__ __forceinline__ void fft_pass(cf* s, int j, const cf* __restrict__ tw
   __syncthreads();
 }
 
-template <int N, int SIGN, int Ns>
+template <int N, int E, int SIGN, int Ns>
 __device__ __forceinline__ void fft_rec(cf* s, int j, const cf* __restrict__ tw) {
   if constexpr (Ns < N) {
     constexpr int rem = N / Ns;
     constexpr int R = rem >= 8 ? 8 : rem;
-    fft_pass<N, R, SIGN, Ns>(s, j, tw);
-    fft_rec<N, SIGN, Ns * R>(s, j, tw);
+    fft_pass<N, E, R, SIGN, Ns>(s, j, tw);
+    fft_rec<N, E, SIGN, Ns * R>(s, j, tw);
   }
 }
 
-// In-LDS N-point FFT; the data must be in place and the workgroup synchronised on entry.
-template <int N, int SIGN>
+// In-LDS N-point FFT by N/E threads (j = thread index within the FFT); the data must be in place
+// and the workgroup synchronised on entry.
+template <int N, int SIGN, int E = 8>
 __device__ __forceinline__ void fft_lds(cf* s, int j, const cf* __restrict__ tw) {
-  fft_rec<N, SIGN, 1>(s, j, tw);
+  fft_rec<N, E, SIGN, 1>(s, j, tw);
 }
 
 template <int N>
@@ -155,6 +147,8 @@ struct FftGeom {
   static constexpr int PADN = N + N / 8;                      // padded LDS points per FFT
   static constexpr int G = (256 / NT) > 1 ? (256 / NT) : 1;   // row FFTs per workgroup
   static constexpr int TC = (8192 / N) < 16 ? (8192 / N) : 16;  // columns per workgroup
+  static constexpr int CE = N >= 128 ? 16 : 8;                // points per thread in the column kernel
+  static constexpr int CNT = N / CE;                          // threads per column FFT
   static constexpr int CS = PADN + 4;                         // LDS stride between columns
 };
 
@@ -209,29 +203,29 @@ __global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_r2c_kernel
 // mode 1: forward FFT, P = G * conj(F) * scale (DC = 0, optional /|P|), store P to R (if R),
 //         inverse FFT, store back to F in place.
 template <int N>
-__global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::NT) void cols_kernel(
+__global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_kernel(
     cf* __restrict__ F, long long F_stride, const cf* __restrict__ Gref, cf* __restrict__ R, long long R_stride,
     int Wp, const cf* __restrict__ tw, int mode, int normalize, float scale) {
   using Gm = FftGeom<N>;
-  constexpr int NTH = Gm::TC * Gm::NT;
+  constexpr int NTH = Gm::TC * Gm::CNT;
   extern __shared__ cf lds_c[];
   const int tid = threadIdx.x;
-  const int c = tid / Gm::NT, j = tid % Gm::NT;
+  const int c = tid / Gm::CNT, j = tid % Gm::CNT;
   cf* s = lds_c + c * Gm::CS;
   const int v0 = xcd_remap(blockIdx.x, gridDim.x) * Gm::TC;
   cf* Ff = F + (size_t)blockIdx.y * F_stride;
-#pragma unroll
-  for (int m = 0; m < 8; ++m) {
+#pragma unroll 4
+  for (int m = 0; m < Gm::CE; ++m) {
     int idx = tid + m * NTH;
     int cc = idx % Gm::TC, u = idx / Gm::TC;
     lds_c[cc * Gm::CS + padi(u)] = Ff[(size_t)u * Wp + v0 + cc];
   }
   __syncthreads();
-  fft_lds<N, -1>(s, j, tw);
+  fft_lds<N, -1, Gm::CE>(s, j, tw);
   if (mode == 1) {
     cf* Rf = R ? R + (size_t)blockIdx.y * R_stride : nullptr;
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
+#pragma unroll 4
+    for (int m = 0; m < Gm::CE; ++m) {
       int idx = tid + m * NTH;
       int cc = idx % Gm::TC, u = idx / Gm::TC;
       cf g = lds_c[cc * Gm::CS + padi(u)];
@@ -248,10 +242,10 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::NT) void cols_kernel(
       lds_c[cc * Gm::CS + padi(u)] = p;
     }
     __syncthreads();
-    fft_lds<N, +1>(s, j, tw);
+    fft_lds<N, +1, Gm::CE>(s, j, tw);
   }
-#pragma unroll
-  for (int m = 0; m < 8; ++m) {
+#pragma unroll 4
+  for (int m = 0; m < Gm::CE; ++m) {
     int idx = tid + m * NTH;
     int cc = idx % Gm::TC, u = idx / Gm::TC;
     Ff[(size_t)u * Wp + v0 + cc] = lds_c[cc * Gm::CS + padi(u)];
@@ -437,19 +431,28 @@ __global__ __launch_bounds__(256) void upsample_finish_kernel(const float* __res
   __shared__ float V[UP_N * UP_N];
   const int frame = blockIdx.x, tid = threadIdx.x;
   if (tid < UP_N * UP_N) {
+    // fixed summation order (deterministic); loads are issued 8 at a time to hide their latency
+    const float* pp = part + (size_t)frame * nchunks * (UP_N * UP_N) + tid;
     float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += part[((size_t)frame * nchunks + c) * (UP_N * UP_N) + tid];
+    int c = 0;
+    for (; c + 8 <= nchunks; c += 8) {
+      float t[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t[q] = pp[(size_t)(c + q) * (UP_N * UP_N)];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += t[q];
+    }
+    for (; c < nchunks; ++c) s += pp[(size_t)c * (UP_N * UP_N)];
     V[tid] = s;
   }
   __syncthreads();
+  __shared__ float shv[16];
+  __shared__ int shi[16];
+  float bv = tid < UP_N * UP_N ? V[tid] : -INFINITY;
+  int best = tid < UP_N * UP_N ? tid : 0x7fffffff;
+  block_argmax(bv, best, shv, shi);   // first maximum in row-major order, as np.argmax
   if (tid == 0) {
-    int best = 0;
-    float bv = V[0];
-    for (int i = 1; i < UP_N * UP_N; ++i)
-      if (V[i] > bv) {
-        bv = V[i];
-        best = i;
-      }
+    if (best == 0x7fffffff) best = UP_HALF * UP_N + UP_HALF;
     int iy = best / UP_N, ix = best - iy * UP_N;
     int2 cs = coarse[frame];
     double cy = (double)cs.x + (double)(iy - UP_HALF) * 0.1;
@@ -886,7 +889,7 @@ static int launch_cols(const RegPlan& p, cf* F, long long F_stride, const cf* Gr
     using Gm = FftGeom<N>;
     size_t lds = (size_t)Gm::TC * Gm::CS * sizeof(cf);
     IAP_HIP(allow_lds(cols_kernel<N>, lds));
-    { ProfScope ps_(K_COLS, st); hipLaunchKernelGGL(cols_kernel<N>, dim3(p.col_blocks, n), dim3(Gm::TC * Gm::NT), lds, st, F, F_stride, Gref, R,
+    { ProfScope ps_(K_COLS, st); hipLaunchKernelGGL(cols_kernel<N>, dim3(p.col_blocks, n), dim3(Gm::TC * Gm::CNT), lds, st, F, F_stride, Gref, R,
                        R_stride, p.Wp, tw_y, mode, normalize, scale); }
   });
   IAP_LAUNCH_CHECK();

@@ -226,7 +226,7 @@ def gauss_blur(planes: torch.Tensor, ksize=(15, 15), sigma: float = 5.0) -> torc
 
 # ----------------------------------------------------------------------------- registration
 
-DEFAULT_REG_BATCH = 8
+DEFAULT_REG_BATCH = 16
 
 
 def mip(stack: torch.Tensor) -> torch.Tensor:
