@@ -171,7 +171,7 @@ __device__ __forceinline__ float load_src(const void* __restrict__ p, int kind, 
 template <int N>
 __global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_r2c_kernel(
     const void* __restrict__ src, int kind, long long plane_stride, int srcX, int oy, int ox, float in_scale,
-    cf* __restrict__ F, long long F_stride, int Wp, const cf* __restrict__ tw) {
+    cf* __restrict__ F, long long F_stride, int Wp, const cf* __restrict__ tw, int vec) {
   using Gm = FftGeom<N>;
   extern __shared__ cf lds_c[];
   const int g = threadIdx.x / Gm::NT, j = threadIdx.x % Gm::NT;
@@ -181,10 +181,17 @@ __global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_r2c_kernel
   const size_t base = (size_t)blockIdx.y * plane_stride;
   const size_t offa = base + (size_t)(oy + ra) * srcX + ox;
   const size_t offb = offa + srcX;
+  if (vec) {  // u16 source, 16-byte aligned rows: one 8-pixel vector per row and thread
+    const uint16_t* p16 = reinterpret_cast<const uint16_t*>(src);
+    u16x8 qa = load8(p16 + offa + 8 * j), qb = load8(p16 + offb + 8 * j);
 #pragma unroll
-  for (int m = 0; m < 8; ++m) {
-    int n = j + m * Gm::NT;
-    s[padi(n)] = make_float2(load_src(src, kind, offa + n) * in_scale, load_src(src, kind, offb + n) * in_scale);
+    for (int k = 0; k < 8; ++k) s[padi(8 * j + k)] = make_float2((float)qa.v[k] * in_scale, (float)qb.v[k] * in_scale);
+  } else {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      int n = j + m * Gm::NT;
+      s[padi(n)] = make_float2(load_src(src, kind, offa + n) * in_scale, load_src(src, kind, offb + n) * in_scale);
+    }
   }
   __syncthreads();
   fft_lds<N, -1>(s, j, tw);
@@ -871,12 +878,13 @@ static hipError_t allow_lds(K kernel, size_t bytes) {
 
 static int launch_rows_r2c(const RegPlan& p, const void* src, int kind, long long plane_stride, float in_scale,
                            cf* F, long long F_stride, int n, const cf* tw_x, hipStream_t st) {
+  const int vec = kind == 0 && aligned16(src) && p.X % 8 == 0 && p.ox % 8 == 0 && plane_stride % 8 == 0;
   IAP_FOR_N(p.Px, {
     using Gm = FftGeom<N>;
     size_t lds = (size_t)Gm::G * Gm::PADN * sizeof(cf);
     IAP_HIP(allow_lds(rows_r2c_kernel<N>, lds));
     { ProfScope ps_(K_ROWS_R2C, st); hipLaunchKernelGGL(rows_r2c_kernel<N>, dim3(p.row_blocks, n), dim3(Gm::G * Gm::NT), lds, st, src, kind,
-                       plane_stride, p.X, p.oy, p.ox, in_scale, F, F_stride, p.Wp, tw_x); }
+                       plane_stride, p.X, p.oy, p.ox, in_scale, F, F_stride, p.Wp, tw_x, vec); }
   });
   IAP_LAUNCH_CHECK();
   return IAP_OK;
