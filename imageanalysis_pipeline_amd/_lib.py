@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libiap_hip.so")
+LIB_PATH = os.environ.get("IAP_LIB") or os.path.join(_HERE, "libiap_hip.so")
 
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 

@@ -352,10 +352,20 @@ __global__ __launch_bounds__(256) void coarse_finish_kernel(const float* __restr
 }
 
 // K5 ---------------------------------------------------------------------------------------
+// Matrix-DFT of the cross-power spectrum on the 15 x 15 grid of 0.1 px offsets round the coarse
+// peak:  V[j][k] = Re sum_{u,v} w_v R[u][v] ey[u][j] ex[v][k],  ey[u][7 +- m] = base_u (a_m +- i b_m)
+// with base_u = exp(2 pi i fu sy / Py) and a_m + i b_m = exp(2 pi i fu 0.1 m / Py) (same along x).
+// The +-m symmetry halves the work: with c = R base, A_m = sum c a_m and B_m = sum c b_m are
+// complex-times-real sums and T[7 +- m] = A_m +- i B_m.
 constexpr int UP_N = 15;       // grid points per axis: offsets -0.7 .. 0.7
 constexpr int UP_HALF = 7;
 constexpr float UP_STEP = 0.1f;
-constexpr int UP_UB = 64;      // spectrum rows per workgroup
+constexpr int UP_UB_MIN = 64;  // fewest spectrum rows a workgroup takes
+constexpr int UP_YS = 16;      // floats per row record   {base.x, base.y, a1..a7, b1..b7}  (one 64-byte scalar load)
+constexpr int UP_XS = 20;      // floats per column record {w base.x, w base.y, 0, 0 | 1, a1..a7 | b1..b7, 0}
+constexpr int UP_NV = UP_N * UP_N;  // 225 grid values
+constexpr int UP_NQ = 32;      // floats per Nyquist-column partial: {ctr, A1..A7, B1..B7} as complex pairs, padded
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ cf unit_phase(int freq, int ishift, int n, float frac_shift) {
   // exp(2 pi i * freq * (ishift + frac_shift) / n); the integer part is reduced exactly
@@ -366,62 +376,228 @@ __device__ __forceinline__ cf unit_phase(int freq, int ishift, int n, float frac
   return make_float2(cs, sn);
 }
 
-__global__ __launch_bounds__(256) void upsample_partial_kernel(const cf* __restrict__ R, long long R_stride, int Wp,
-                                                               int Py, int Px, int ncg,
-                                                               const int2* __restrict__ coarse,
-                                                               float* __restrict__ part) {
-  __shared__ cf ey[UP_UB][UP_N];
-  __shared__ cf Tl[UP_N][256 + 1];
-  __shared__ cf ex[256][UP_N];
+#ifdef IAP_UP_STAMPS
+__device__ long long* g_up_stamps;
+#endif
+
+// T[j] (j = 0..14) from the centre sum and the A/B sums:  T[7] = ctr,  T[7 +- m] = A_m +- i B_m
+__device__ __forceinline__ v2f up_combine(int j, v2f ctr, const v2f* A, const v2f* B) {
+  const int m = j >= UP_HALF ? j - UP_HALF : UP_HALF - j;
+  if (m == 0) return ctr;
+  if (j > UP_HALF) return (v2f){A[m - 1].x - B[m - 1].y, A[m - 1].y + B[m - 1].x};
+  return (v2f){A[m - 1].x + B[m - 1].y, A[m - 1].y - B[m - 1].x};
+}
+
+// Row and column records of every frame of the batch (the coarse shift enters through base
+// only).  The threads that build row records also sum the Nyquist column v = Px/2, which the
+// main kernel's power-of-two column split leaves out: one partial {ctr, A, B} per workgroup.
+__global__ __launch_bounds__(256) void upsample_tables_kernel(int Py, int Px, int Wp, const int2* __restrict__ coarse,
+                                                              const cf* __restrict__ R, long long R_stride,
+                                                              float* __restrict__ yrec, float* __restrict__ xrec,
+                                                              float* __restrict__ nyq, int nyb) {
+  __shared__ float wsum[4][UP_NQ];
+  const int frame = blockIdx.y;
   const int tid = threadIdx.x;
+  const int i = blockIdx.x * 256 + tid;
+  const int2 cs = coarse[frame];
+  v2f ctr = {0.f, 0.f}, A[UP_HALF], B[UP_HALF];
+#pragma unroll
+  for (int m = 0; m < UP_HALF; ++m) A[m] = B[m] = (v2f){0.f, 0.f};
+  if (i < Py) {
+    const int fu = i < Py / 2 ? i : i - Py;
+    const cf r = R[(size_t)frame * R_stride + (size_t)i * Wp + Px / 2];
+    float* o = yrec + ((size_t)frame * Py + i) * UP_YS;
+    const cf bs = unit_phase(fu, cs.x, Py, 0.f);
+    o[0] = bs.x; o[1] = bs.y;
+    ctr = (v2f){fmaf(r.x, bs.x, -(r.y * bs.y)), fmaf(r.x, bs.y, r.y * bs.x)};
+#pragma unroll
+    for (int m = 1; m <= UP_HALF; ++m) {
+      const cf e = unit_phase(fu, 0, Py, (float)m * UP_STEP);
+      o[1 + m] = e.x; o[1 + UP_HALF + m] = e.y;
+      A[m - 1] = (v2f){ctr.x * e.x, ctr.y * e.x};
+      B[m - 1] = (v2f){ctr.x * e.y, ctr.y * e.y};
+    }
+  } else if (i - Py < Wp) {
+    const int v = i - Py;
+    const int fv = v < Px / 2 ? v : v - Px;
+    const float w = v > Px / 2 ? 0.f : ((v == 0 || v == Px / 2) ? 1.f : 2.f);  // Hermitian doubling of the half spectrum
+    float* o = xrec + ((size_t)frame * Wp + v) * UP_XS;
+    const cf bs = unit_phase(fv, cs.y, Px, 0.f);
+    o[0] = w * bs.x; o[1] = w * bs.y; o[2] = 0.f; o[3] = 0.f; o[4] = 1.f; o[UP_XS - 1] = 0.f;
+#pragma unroll
+    for (int m = 1; m <= UP_HALF; ++m) {
+      const cf e = unit_phase(fv, 0, Px, (float)m * UP_STEP);
+      o[4 + m] = e.x; o[11 + m] = e.y;
+    }
+  }
+  if ((int)blockIdx.x < nyb) {  // uniform: this workgroup holds spectrum rows
+#pragma unroll
+    for (int q = 0; q < 2 * UP_N; ++q) {
+      float x = q < 2 ? (q ? ctr.y : ctr.x)
+                      : (q < 16 ? ((q & 1) ? A[(q - 2) >> 1].y : A[(q - 2) >> 1].x)
+                                : ((q & 1) ? B[(q - 16) >> 1].y : B[(q - 16) >> 1].x));
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) x += __shfl_down(x, d, 64);
+      if ((tid & 63) == 0) wsum[tid >> 6][q] = x;
+    }
+    __syncthreads();
+    if (tid < 2 * UP_N)
+      nyq[((size_t)frame * nyb + blockIdx.x) * UP_NQ + tid] =
+          (wsum[0][tid] + wsum[1][tid]) + (wsum[2][tid] + wsum[3][tid]);
+  }
+}
+
+// grid value (j, k) from the P and Q sums, pq[j * 8 + m] = P[j][m] (m = 0..7) and
+// pq[128 + j * 8 + m - 1] = Q[j][m] (m = 1..7):  V[j][7] = P[j][0],  V[j][7 +- m] = P[j][m] -+ Q[j][m]
+__device__ __forceinline__ float up_grid_value(const float* pq, int j, int k) {
+  const int m = k >= UP_HALF ? k - UP_HALF : UP_HALF - k;
+  const float pv = pq[j * 8 + m];
+  if (m == 0) return pv;
+  const float qv = pq[128 + j * 8 + (m - 1)];
+  return k > UP_HALF ? pv - qv : pv + qv;
+}
+
+// One workgroup: 512 spectrum columns (two per thread, v < Px/2) x ub rows.  Row records are
+// wave-uniform and arrive through one 64-byte scalar load per row.  The column sums T[j][v],
+// multiplied by the column base, are then contracted over v in LDS: a lane owns a 4 x 4 block of
+// the P (Re T x a) or Q (Im T x b) sums for every fourth column of its wave's 64, so that two
+// 16-byte LDS reads feed 16 FMAs; lanes, then waves, are summed in fixed order (deterministic).
+__global__ __launch_bounds__(256) void upsample_partial_kernel(const cf* __restrict__ R, long long R_stride, int Wp,
+                                                               int Py, int Px, int ncg, int ub,
+                                                               const float* __restrict__ yrec,
+                                                               const float* __restrict__ xrec,
+                                                               float* __restrict__ part, int slots) {
+  __shared__ __align__(16) float Tl[256][36];  // [column][plane * 16 + j]: Re, Im of T[j][v] base_v; j = 15 is zero
+  __shared__ __align__(16) float Xl[256][16];  // [column]{1, a1..a7, b1..b7, 0}
+  __shared__ float red[4][256];
+  const int tid = threadIdx.x;
+#ifdef IAP_UP_STAMPS
+  const long long t_start = wall_clock64();
+#endif
   const int cg = blockIdx.x % ncg, uc = blockIdx.x / ncg;
   const int frame = blockIdx.y;
-  const int2 cs = coarse[frame];
-  const int u0 = uc * UP_UB;
-  for (int i = tid; i < UP_UB * UP_N; i += 256) {
-    int ul = i / UP_N, jq = i - ul * UP_N;
-    int u = u0 + ul;
-    int fu = u < Py / 2 ? u : u - Py;
-    ey[ul][jq] = unit_phase(fu, cs.x, Py, (float)(jq - UP_HALF) * UP_STEP);
+  const int u0 = uc * ub;
+  const int len = min(ub, Py - u0);  // multiple of 4 (host)
+  const int half = Px / 2;
+  int vcol[2];
+  bool ok[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) { vcol[c] = cg * 512 + c * 256 + tid; ok[c] = vcol[c] < half; }
+  v2f ctr[2], A[2][UP_HALF], B[2][UP_HALF];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    ctr[c] = (v2f){0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < UP_HALF; ++m) A[c][m] = B[c][m] = (v2f){0.f, 0.f};
   }
-  const int v = cg * 256 + tid;
-  const bool valid = v <= Px / 2;
-  const int fv = v < Px / 2 ? v : v - Px;
+  const cf* Rp[2];
 #pragma unroll
-  for (int k = 0; k < UP_N; ++k) ex[tid][k] = unit_phase(fv, 0, Px, (float)(k - UP_HALF) * UP_STEP);
-  __syncthreads();
-  cf acc[UP_N];
+  for (int c = 0; c < 2; ++c) Rp[c] = R + (size_t)frame * R_stride + (size_t)u0 * Wp + (ok[c] ? vcol[c] : 0);
+  const float* __restrict__ yr = yrec + ((size_t)frame * Py + u0) * UP_YS;
+  constexpr int PF = 4;  // rows in flight: the next group's loads are issued before this group's FMAs
+  cf r[2][PF], rn[2][PF];
 #pragma unroll
-  for (int jq = 0; jq < UP_N; ++jq) acc[jq] = make_float2(0.f, 0.f);
-  const cf* Rp = R + (size_t)frame * R_stride + (size_t)u0 * Wp + v;
-  if (valid) {
-    for (int ul = 0; ul < UP_UB; ++ul) {
-      cf r = Rp[(size_t)ul * Wp];
+  for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int jq = 0; jq < UP_N; ++jq) {
-        cf e = ey[ul][jq];
-        acc[jq].x = fmaf(r.x, e.x, fmaf(-r.y, e.y, acc[jq].x));
-        acc[jq].y = fmaf(r.x, e.y, fmaf(r.y, e.x, acc[jq].y));
+    for (int i = 0; i < PF; ++i) r[c][i] = Rp[c][(size_t)i * Wp];
+  for (int ul = 0; ul < len; ul += PF) {
+    const int un = min(ul + PF, len - PF);
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < PF; ++i) rn[c][i] = Rp[c][(size_t)(un + i) * Wp];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const float* __restrict__ rec = yr + (ul + i) * UP_YS;
+      const float bx = rec[0], by = rec[1];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const float t1 = r[c][i].y * by, t2 = r[c][i].y * bx;
+        const v2f cc = {fmaf(r[c][i].x, bx, -t1), fmaf(r[c][i].x, by, t2)};
+        ctr[c] += cc;
+#pragma unroll
+        for (int m = 0; m < UP_HALF; ++m) {
+          const float am = rec[2 + m], bm = rec[2 + UP_HALF + m];
+          A[c][m] = __builtin_elementwise_fma(cc, (v2f){am, am}, A[c][m]);
+          B[c][m] = __builtin_elementwise_fma(cc, (v2f){bm, bm}, B[c][m]);
+        }
       }
     }
-  }
-  // fold the column weight (Hermitian doubling) and the integer-shift phase into T
-  float w = (!valid) ? 0.f : ((v == 0 || v == Px / 2) ? 1.f : 2.f);
-  cf ph = unit_phase(fv, cs.y, Px, 0.f);
-  ph.x *= w;
-  ph.y *= w;
 #pragma unroll
-  for (int jq = 0; jq < UP_N; ++jq) Tl[jq][tid] = cmul(acc[jq], ph);
-  __syncthreads();
-  if (tid < UP_N * UP_N) {
-    const int jq = tid / UP_N, k = tid - jq * UP_N;
-    float sum = 0.f;
-    for (int vv = 0; vv < 256; ++vv) {
-      cf t = Tl[jq][vv], e = ex[vv][k];
-      sum = fmaf(t.x, e.x, fmaf(-t.y, e.y, sum));
-    }
-    part[((size_t)frame * gridDim.x + blockIdx.x) * (UP_N * UP_N) + tid] = sum;
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int i = 0; i < PF; ++i) r[c][i] = rn[c][i];
   }
+#ifdef IAP_UP_STAMPS
+  const long long t_main = wall_clock64();
+#endif
+  // contraction over columns
+  const int wv = tid >> 6, lane = tid & 63, vsub = lane >> 4, blk = lane & 15;
+  const int isq = blk >> 3, j0 = ((blk & 7) >> 1) * 4, m0 = (blk & 1) * 4;
+  float sum[4][4];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+    for (int mm = 0; mm < 4; ++mm) sum[jj][mm] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    if (cg * 512 + c * 256 >= half) break;  // uniform
+    if (c) __syncthreads();                  // the first half's reads are done
+    {
+      const float4* xr = (const float4*)(xrec + ((size_t)frame * Wp + (ok[c] ? vcol[c] : 0)) * UP_XS);
+      const float4 x0 = xr[0];
+      const float bx = ok[c] ? x0.x : 0.f, by = ok[c] ? x0.y : 0.f;  // columns past Px/2 contribute zeros
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *(float4*)&Xl[tid][4 * q] = xr[1 + q];
+      float tre[16], tim[16];
+#pragma unroll
+      for (int j = 0; j < UP_N; ++j) {
+        const v2f t = up_combine(j, ctr[c], A[c], B[c]);
+        tre[j] = fmaf(t.x, bx, -(t.y * by));
+        tim[j] = fmaf(t.x, by, t.y * bx);
+      }
+      tre[15] = tim[15] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        *(float4*)&Tl[tid][4 * q] = make_float4(tre[4 * q], tre[4 * q + 1], tre[4 * q + 2], tre[4 * q + 3]);
+        *(float4*)&Tl[tid][16 + 4 * q] = make_float4(tim[4 * q], tim[4 * q + 1], tim[4 * q + 2], tim[4 * q + 3]);
+      }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int vv = wv * 64 + it * 4 + vsub;
+      const float4 t = *(const float4*)&Tl[vv][isq * 16 + j0];
+      const float4 xc = *(const float4*)&Xl[vv][isq * 8 + m0];
+      const float tv[4] = {t.x, t.y, t.z, t.w}, xv[4] = {xc.x, xc.y, xc.z, xc.w};
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) sum[jj][mm] = fmaf(tv[jj], xv[mm], sum[jj][mm]);
+    }
+  }
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+    for (int mm = 0; mm < 4; ++mm) {
+      float x = sum[jj][mm];
+      x += __shfl_xor(x, 16, 64);
+      x += __shfl_xor(x, 32, 64);
+      if (vsub == 0) red[wv][isq * 128 + (j0 + jj) * 8 + m0 + mm] = x;
+    }
+  __syncthreads();
+  red[0][tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+  __syncthreads();
+  if (tid < UP_NV) {
+    const int j = tid / UP_N, k = tid - j * UP_N;
+    part[((size_t)frame * slots + blockIdx.x) * UP_NV + tid] = up_grid_value(&red[0][0], j, k);
+  }
+#ifdef IAP_UP_STAMPS
+  if (tid == 0) {
+    long long* o = g_up_stamps + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+    o[0] = t_start; o[1] = t_main; o[2] = wall_clock64(); o[3] = 0;
+  }
+#endif
 }
 
 // K6 ---------------------------------------------------------------------------------------
@@ -433,10 +609,19 @@ __device__ __forceinline__ double parabola(double vm, double v0, double vp) {
 }
 
 __global__ __launch_bounds__(256) void upsample_finish_kernel(const float* __restrict__ part, int nchunks,
+                                                              const float* __restrict__ nyq, int nyb,
+                                                              const float* __restrict__ xrec, int Wp, int Px,
                                                               const int2* __restrict__ coarse,
                                                               double* __restrict__ shifts) {
   __shared__ float V[UP_N * UP_N];
+  __shared__ float nq[UP_NQ];
   const int frame = blockIdx.x, tid = threadIdx.x;
+  if (tid < UP_NQ) {
+    float s = 0.f;
+    for (int b = 0; b < nyb; ++b) s += nyq[((size_t)frame * nyb + b) * UP_NQ + tid];
+    nq[tid] = s;
+  }
+  __syncthreads();
   if (tid < UP_N * UP_N) {
     // fixed summation order (deterministic); loads are issued 8 at a time to hide their latency
     const float* pp = part + (size_t)frame * nchunks * (UP_N * UP_N) + tid;
@@ -450,6 +635,15 @@ __global__ __launch_bounds__(256) void upsample_finish_kernel(const float* __res
       for (int q = 0; q < 8; ++q) s += t[q];
     }
     for (; c < nchunks; ++c) s += pp[(size_t)c * (UP_N * UP_N)];
+    {  // the Nyquist column (weight 1): single-term P and Q sums
+      const int j = tid / UP_N, k = tid - j * UP_N;
+      const float* xr = xrec + ((size_t)frame * Wp + Px / 2) * UP_XS;
+      const v2f t = up_combine(j, (v2f){nq[0], nq[1]}, (const v2f*)&nq[2], (const v2f*)&nq[16]);
+      const float cx = fmaf(t.x, xr[0], -(t.y * xr[1])), cy = fmaf(t.x, xr[1], t.y * xr[0]);
+      const int m = k >= UP_HALF ? k - UP_HALF : UP_HALF - k;
+      const float pv = cx * xr[4 + m], qv = m ? cy * xr[11 + m] : 0.f;
+      s += k > UP_HALF ? pv - qv : pv + qv;
+    }
     V[tid] = s;
   }
   __syncthreads();
@@ -801,8 +995,8 @@ static bool make_plan(int Y, int X, RegPlan& p) {
   p.spec = (size_t)p.Py * p.Wp;
   p.row_blocks = p.Py / 2 / geom_rows_G(p.Px);
   p.col_blocks = p.Wp / geom_TC(p.Py);
-  p.ncg = (p.Px / 2 + 1 + 255) / 256;
-  p.nuc = p.Py / UP_UB;
+  p.ncg = (p.Px / 2 + 511) / 512;
+  p.nuc = std::max(1, p.Py / UP_UB_MIN);  // most row chunks a launch may use (sizes the partials)
   return true;
 }
 
@@ -812,6 +1006,8 @@ struct RegWs {
   int* pidx;
   int2* coarse;
   float* upart;
+  float *yrec, *xrec;  // upsample row / column records per frame
+  float* nyq;          // Nyquist-column partial sums per frame
   uint16_t *mip, *mip_ref;
   uint32_t* sum;
   int batch;
@@ -825,7 +1021,8 @@ static size_t reg_fixed_bytes(const RegPlan& p) {
 }
 static size_t reg_frame_bytes(const RegPlan& p, int Z) {
   size_t b = 2 * align256(p.spec * 8) + 2 * align256((size_t)p.row_blocks * 4) + 256 +
-             align256((size_t)p.ncg * p.nuc * UP_N * UP_N * 4);
+             align256((size_t)p.ncg * p.nuc * UP_NV * 4) + align256((size_t)p.Py * UP_YS * 4) +
+             align256((size_t)p.Wp * UP_XS * 4) + align256((size_t)((p.Py + 255) / 256) * UP_NQ * 4);
   if (Z > 1) b += align256((size_t)p.Y * p.X * 2);
   return b;
 }
@@ -852,7 +1049,10 @@ static bool carve(void* ws, size_t bytes, const RegPlan& p, int Z, RegWs& w) {
   w.pval = (float*)take((size_t)batch * p.row_blocks * 4);
   w.pidx = (int*)take((size_t)batch * p.row_blocks * 4);
   w.coarse = (int2*)take((size_t)batch * 8);
-  w.upart = (float*)take((size_t)batch * p.ncg * p.nuc * UP_N * UP_N * 4);
+  w.upart = (float*)take((size_t)batch * p.ncg * p.nuc * UP_NV * 4);
+  w.nyq = (float*)take((size_t)batch * ((p.Py + 255) / 256) * UP_NQ * 4);
+  w.yrec = (float*)take((size_t)batch * p.Py * UP_YS * 4);
+  w.xrec = (float*)take((size_t)batch * p.Wp * UP_XS * 4);
   w.mip = Z > 1 ? (uint16_t*)take((size_t)batch * p.Y * p.X * 2) : nullptr;
   return true;
 }
@@ -932,6 +1132,22 @@ static int reg_ref_spectrum(const RegPlan& p, RegWs& w, const void* ref, int kin
 }
 
 // shifts for n moving planes (n <= w.batch) against w.refspec
+// Workgroups of upsample_partial_kernel the current device holds at once.
+static int upsample_capacity() {
+  static int cap[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1024;
+  if (!cap[dev]) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, upsample_partial_kernel, 256, 0) != hipSuccess || per_cu < 1)
+      per_cu = 2;
+    if (const char* e = getenv("IAP_UP_WGS")) per_cu = std::max(1, std::min(per_cu, atoi(e)));
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    cap[dev] = per_cu * cus;
+  }
+  return cap[dev];
+}
+
 static int reg_estimate_batch(const RegPlan& p, RegWs& w, const uint16_t* mov, long long mov_stride, int n, int flags,
                               double* shifts, hipStream_t st) {
   const long long fs = (long long)(align256(p.spec * 8) / 8);
@@ -946,10 +1162,19 @@ static int reg_estimate_batch(const RegPlan& p, RegWs& w, const uint16_t* mov, l
   { ProfScope ps_(K_COARSE, st); hipLaunchKernelGGL(coarse_finish_kernel, dim3(n), dim3(256), 0, st, (const float*)w.pval, (const int*)w.pidx,
                      p.row_blocks, p.Py, p.Px, w.coarse, shifts, up ? 0 : 1); }
   if (up) {
-    int nch = p.ncg * p.nuc;
-    { ProfScope ps_(K_UPSAMPLE, st); hipLaunchKernelGGL(upsample_partial_kernel, dim3(nch, n), dim3(256), 0, st, (const cf*)w.R, fs, p.Wp, p.Py, p.Px,
-                       p.ncg, (const int2*)w.coarse, w.upart); }
+    // row chunks (multiples of 4 rows) sized so that the whole launch is resident at once
+    int nuc = std::min(p.nuc, std::max(1, upsample_capacity() / (n * p.ncg)));
+    const int ub = (((p.Py + nuc - 1) / nuc) + 3) & ~3;
+    nuc = (p.Py + ub - 1) / ub;
+    const int nch = p.ncg * nuc, nyb = (p.Py + 255) / 256;
+    { ProfScope ps_(K_OTHER, st);
+      hipLaunchKernelGGL(upsample_tables_kernel, dim3((p.Py + p.Wp + 255) / 256, n), dim3(256), 0, st, p.Py, p.Px, p.Wp,
+                         (const int2*)w.coarse, (const cf*)w.R, fs, w.yrec, w.xrec, w.nyq, nyb); }
+    { ProfScope ps_(K_UPSAMPLE, st);
+      hipLaunchKernelGGL(upsample_partial_kernel, dim3(nch, n), dim3(256), 0, st, (const cf*)w.R, fs, p.Wp, p.Py, p.Px,
+                         p.ncg, ub, (const float*)w.yrec, (const float*)w.xrec, w.upart, nch); }
     { ProfScope ps_(K_UPFINISH, st); hipLaunchKernelGGL(upsample_finish_kernel, dim3(n), dim3(256), 0, st, (const float*)w.upart, nch,
+                         (const float*)w.nyq, nyb, (const float*)w.xrec, p.Wp, p.Px,
                        (const int2*)w.coarse, shifts); }
   }
   IAP_LAUNCH_CHECK();
