@@ -143,7 +143,7 @@ def collect_kernel_times():
     return out
 
 
-def cpu_baseline(y, x, c, n_cells, budget_frames=2):
+def cpu_baseline(y, x, c, n_cells, budget_frames=6):
     """The oracle (numpy restatement of the reference CPU path) on a bounded sample of the workload:
     `budget_frames` frames x C channels of the same plane size, same stages."""
     from oracle import ref_path as O
