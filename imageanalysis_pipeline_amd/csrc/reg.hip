@@ -718,10 +718,19 @@ __global__ __launch_bounds__(256) void accum_planes_kernel(const uint16_t* __res
 // scalar loads at the image border.
 constexpr int AP_R = 11;
 constexpr int AP_TX = 64;
-constexpr int AP_TW = 96;                   // staged columns: 12 aligned u16x8 vectors
-constexpr int AP_PITCH = 97;                // floats; == 1 mod 32 -> row-major lanes hit distinct banks
-constexpr int AP_RP = AP_TX + 1;            // pitch of the x-filtered tile
+constexpr int AP_TW = 96;      // staged columns, starting at the first sample the tile needs: 12 u16x8 vectors
+constexpr int AP_PITCH = 104;  // u16 per staged row = 52 dwords = 4 * odd: 16-byte reads by lanes on consecutive rows hit distinct banks
+constexpr int AP_XG = 16;      // outputs per thread in the x pass
 constexpr float AP_Z1 = -0.26794919243112270647f;
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_px __attribute__((aligned(2)));  // 16-byte load at any pixel address
+#ifdef IAP_AP_STAMPS
+__device__ unsigned long long g_ap_stamps[8];
+#define AP_STAMP(i) do { long long t_ = clock64(); t_acc[i] += t_ - t_last; t_last = t_; } while (0)
+#else
+#define AP_STAMP(i) do {} while (0)
+#endif
 
 struct AxisParams {
   int sh;      // integer part of the source offset: i0 = i + sh
@@ -773,8 +782,10 @@ __device__ __forceinline__ void spline_run(const float* s, const float (&w)[4], 
   }
 #pragma unroll
   for (int q = NC - 2; q >= 0; --q) cm[q] = fmaf(cm[q + 1], AP_Z1, s[AP_R + q]);
+  // coefficient / c0 = C+ + C- - s, and C-[q] - s[q] = z1 C-[q+1]: one FMA per coefficient
+  cp[NC - 1] = (cp[NC - 1] + cm[NC - 1]) - s[AP_R + NC - 1];
 #pragma unroll
-  for (int q = 0; q < NC; ++q) cp[q] = (cp[q] + cm[q]) - s[AP_R + q];   // coefficient / c0
+  for (int q = 0; q < NC - 1; ++q) cp[q] = fmaf(cm[q + 1], AP_Z1, cp[q]);
 #pragma unroll
   for (int k = 0; k < NOUT; ++k)
     out[k] = fmaf(w[0], cp[k], fmaf(w[1], cp[k + 1], fmaf(w[2], cp[k + 2], w[3] * cp[k + 3])));
@@ -783,16 +794,23 @@ __device__ __forceinline__ void spline_run(const float* s, const float (&w)[4], 
 template <int TY>
 __global__ __launch_bounds__(256) void apply_shift_kernel(const uint16_t* __restrict__ in,
                                                           uint16_t* __restrict__ out, long long planes_per_frame,
-                                                          int Y, int X, const double* __restrict__ shifts,
-                                                          int vec_ok, int ntx) {
-  constexpr int TH = TY + 2 * AP_R + 3;        // staged rows
-  constexpr int YG = TY / 4;                   // outputs per thread in the y pass (4 row groups x 64 columns)
-  constexpr int NVEC = TH * (AP_TW / 8);       // 16-byte vectors per staged tile
-  constexpr int NV = (NVEC + 255) / 256;       // ... per thread
-  __shared__ float tile[TH * AP_PITCH];        // input tile; reused as the u32 output tile
-  __shared__ float rowp[TH * AP_RP];           // after the x pass
+                                                          int Y, int X, const double* __restrict__ shifts, int ntx) {
+  constexpr int TH = TY + 2 * AP_R + 3;                  // staged rows
+  constexpr int YG = TY / 4;                             // outputs per thread in the y pass (4 row groups x 64 columns)
+  constexpr int XS = (AP_XG + 2 * AP_R + 3 + 7) & ~7;    // samples an x run reads (whole 16-byte vectors of u16)
+  constexpr int YS = (YG + 2 * AP_R + 3 + 3) & ~3;       // samples a y run reads
+  constexpr int CP0 = (TY - YG + YS + 3) & ~3;
+  constexpr int CP = (CP0 / 4) % 2 ? CP0 : CP0 + 4;      // pitch of the transposed x-filtered tile: 4 * odd
+  constexpr int NVEC = TH * (AP_TW / 8);                 // 16-byte vectors per staged tile
+  constexpr int NV = (NVEC + 255) / 256;                 // ... per thread
+  static_assert((AP_TX / AP_XG - 1) * AP_XG + XS <= AP_TW, "x runs stay inside the staged columns");
+  __shared__ __align__(16) uint16_t tile[TH * AP_PITCH]; // source tile; column 0 = first sample needed
+  __shared__ __align__(16) float colp[AP_TX * CP];       // after the x pass, transposed: [column][row]
   __shared__ AxisParams pay, pax;
   const int tid = threadIdx.x;
+#ifdef IAP_AP_STAMPS
+  long long t_last = clock64(), t_acc[6] = {0, 0, 0, 0, 0, 0};
+#endif
   const long long plane = blockIdx.z;
   const long long frame = plane / planes_per_frame;
   if (tid < 2) {
@@ -814,145 +832,160 @@ __global__ __launch_bounds__(256) void apply_shift_kernel(const uint16_t* __rest
   const int tx0 = bxi * ntx, tx1 = min(tx0 + ntx, tiles_x);
   const bool rows_valid = !(oy > ay.hi || yend - 1 < ay.lo);
   const int row0 = oy + ay.sh - 1 - AP_R;
+  const bool wide = X >= 8;  // a 16-byte load fits in a row
 
   // this thread's staged vectors: (row, vector) are the same for every tile of the run
-  size_t voff[NV];
-  int lds_off[NV];
+  size_t rowoff[NV];
+  int v8[NV], lds_off[NV];
 #pragma unroll
   for (int jv = 0; jv < NV; ++jv) {
     int i = min(tid + jv * 256, NVEC - 1);       // clamped, so every load is unconditional
     int r = i / (AP_TW / 8), v = i - r * (AP_TW / 8);
     int yy = row0 + r;
     if (yy < 0 || yy >= Y) yy = rows_valid ? reflect101_idx(yy, Y) : 0;
-    voff[jv] = (size_t)yy * X + 8 * v;
+    rowoff[jv] = (size_t)yy * X;
+    v8[jv] = 8 * v;
     lds_off[jv] = r * AP_PITCH + 8 * v;
   }
-  u16x8 q[NV];
-  auto geom = [&](int tx, int& a0, int& o, bool& fast, bool& valid) {
+  u32x4 q[NV];  // kept opaque so that the loads stay in flight until the tile is staged
+  auto geom = [&](int tx, int& first, bool& valid) {
     const int ox = tx * AP_TX;
-    const int first = ox + ax.sh - 1 - AP_R;
-    a0 = first & ~7;                             // arithmetic: rounds toward -inf for negatives too
-    o = first - a0;
+    first = ox + ax.sh - 1 - AP_R;
     valid = rows_valid && !(ox > ax.hi || min(ox + AP_TX, X) - 1 < ax.lo);
-    fast = valid && vec_ok && a0 >= 0 && a0 + AP_TW <= X;
   };
-  auto preload = [&](int a0) {
+  auto preload = [&](int first) {  // vectors that stick out of the row are re-read element-wise when staged
 #pragma unroll
-    for (int jv = 0; jv < NV; ++jv) q[jv] = load8(p + voff[jv] + a0);
+    for (int jv = 0; jv < NV; ++jv) {
+#ifdef IAP_AP_NOLOAD
+      const int cl = 0 * first;
+#else
+      const int cl = min(max(first + v8[jv], 0), X - 8);
+#endif
+      q[jv] = *reinterpret_cast<const u32x4_px*>(p + rowoff[jv] + cl);
+    }
+  };
+  auto stage = [&](int first) {  // the source tile as raw u16 (its readers convert)
+#pragma unroll
+    for (int jv = 0; jv < NV; ++jv) {
+      if (tid + jv * 256 < NVEC) {
+        const int col0 = first + v8[jv];
+        u32x4 w8;
+        if (wide && col0 >= 0 && col0 + 8 <= X) {
+          w8 = q[jv];
+        } else {  // image border: mirrored scalar loads
+          unsigned e[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) e[k] = p[rowoff[jv] + reflect101_idx(col0 + k, X)];
+          w8 = (u32x4){e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+        }
+        *reinterpret_cast<u32x4*>(tile + lds_off[jv]) = w8;
+      }
+    }
   };
   {
-    int a0, o;
-    bool fast, valid;
-    geom(tx0, a0, o, fast, valid);
-    if (fast) preload(a0);
+    int first;
+    bool valid;
+    geom(tx0, first, valid);
+    if (valid) {
+      if (wide) preload(first);
+      stage(first);
+    }
   }
+  AP_STAMP(0);
 
+  // Per tile: barrier A | issue the next tile's loads | x pass (tile -> colp) | barrier B | stage the
+  // next tile | y pass + stores.  The next tile is staged BEFORE this tile's stores are issued:
+  // waiting for its loads (vmcnt counts in order) then never waits for a store.
   for (int tx = tx0; tx < tx1; ++tx) {
     const int ox = tx * AP_TX;
-    int a0, o;
-    bool fast, valid;
-    geom(tx, a0, o, fast, valid);
-    int na0 = 0, no = 0;
-    bool nfast = false, nvalid = false;
-    if (tx + 1 < tx1) geom(tx + 1, na0, no, nfast, nvalid);
+    int first, nfirst = 0;
+    bool valid, nvalid = false;
+    geom(tx, first, valid);
+    if (tx + 1 < tx1) geom(tx + 1, nfirst, nvalid);
 
     if (!valid) {  // no output of this tile has its source inside the image: zeros
       for (int i = tid; i < TY * AP_TX; i += 256) {
         int r = i / AP_TX, c = i - r * AP_TX;
         if (oy + r < Y && ox + c < X) po[(size_t)(oy + r) * X + ox + c] = 0;
       }
-      if (nfast) preload(na0);
+      if (nvalid) {  // `tile` is free: its last readers passed barrier B of an earlier tile
+        if (wide) preload(nfirst);
+        stage(nfirst);
+      }
       continue;
     }
+    __syncthreads();   // A: the staged tile is visible, colp is free
+    AP_STAMP(1);
+    if (nvalid && wide) preload(nfirst);
 
-    // ---- stage the source tile as float
-    if (fast) {
+    // ---- x pass: TH rows x 4 runs of 16 outputs; lanes run along rows; result stored transposed
+    for (int i = tid; i < TH * (AP_TX / AP_XG); i += 256) {
+      const int m = i / TH, r = i - m * TH;
+      const u16x8* t = reinterpret_cast<const u16x8*>(tile + r * AP_PITCH + AP_XG * m);
+      float s[XS];
 #pragma unroll
-      for (int jv = 0; jv < NV; ++jv) {
-        if (tid + jv * 256 < NVEC) {
-          float* t = tile + lds_off[jv];
+      for (int k = 0; k < XS / 8; ++k) {
+        const u16x8 v8r = t[k];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) t[k] = (float)q[jv].v[k];
-        }
+        for (int e = 0; e < 8; ++e) s[8 * k + e] = (float)v8r.v[e];
       }
-    } else {  // image border (or unaligned pitch): mirrored scalar loads
-      for (int i = tid; i < TH * AP_TW; i += 256) {
-        int r = i / AP_TW, c = i - r * AP_TW;
-        int yy = reflect101_idx(row0 + r, Y);
-        int xx = reflect101_idx(a0 + c, X);
-        tile[r * AP_PITCH + c] = (float)p[(size_t)yy * X + xx];
-      }
-    }
-    __syncthreads();
-    if (nfast) preload(na0);   // next tile's loads fly while this one is filtered
-
-    // ---- x pass: TH rows x 8 groups of 8 outputs; lanes run along rows (bank-conflict free)
-    for (int i = tid; i < TH * 8; i += 256) {
-      int m = i / TH, r = i - m * TH;
-      const float* t = tile + r * AP_PITCH + o + 8 * m;
-      float res[8];
+      float res[AP_XG];
       if (ax.whole) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) res[k] = t[AP_R + 1 + k];
+        for (int k = 0; k < AP_XG; ++k) res[k] = s[AP_R + 1 + k];
       } else {
-        float s[8 + 2 * AP_R + 3];
-#pragma unroll
-        for (int k = 0; k < 8 + 2 * AP_R + 3; ++k) s[k] = t[k];
-        spline_run<8>(s, ax.w, res);
+        spline_run<AP_XG>(s, ax.w, res);
       }
-      float* d = rowp + r * AP_RP + 8 * m;
+      float* d = colp + (AP_XG * m) * CP + r;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) d[k] = res[k];
+      for (int k = 0; k < AP_XG; ++k) d[k * CP] = res[k];
     }
-    __syncthreads();
+    AP_STAMP(2);
+    __syncthreads();   // B: colp is visible, the tile is free
+    AP_STAMP(3);
+    if (nvalid) stage(nfirst);
+    AP_STAMP(4);
 
-    // ---- y pass: one column per lane, YG consecutive rows per thread; results -> u32 tile in LDS
-    unsigned* otile = reinterpret_cast<unsigned*>(tile);
+    // ---- y pass: one column per lane, YG consecutive rows per thread, stored straight to the
+    // plane (a wave writes 64 neighbouring pixels of one row per store)
     {
       const int c = tid & 63, y0 = (tid >> 6) * YG;
-      const float* t = rowp + y0 * AP_RP + c;
+      const float4* t = reinterpret_cast<const float4*>(colp + c * CP + y0);
+      float s[YS];
+#pragma unroll
+      for (int k = 0; k < YS / 4; ++k) {
+        const float4 v4 = t[k];
+        s[4 * k] = v4.x; s[4 * k + 1] = v4.y; s[4 * k + 2] = v4.z; s[4 * k + 3] = v4.w;
+      }
       float res[YG];
       if (ay.whole) {
 #pragma unroll
-        for (int k = 0; k < YG; ++k) res[k] = t[(AP_R + 1 + k) * AP_RP];
+        for (int k = 0; k < YG; ++k) res[k] = s[AP_R + 1 + k];
       } else {
-        float s[YG + 2 * AP_R + 3];
-#pragma unroll
-        for (int k = 0; k < YG + 2 * AP_R + 3; ++k) s[k] = t[k * AP_RP];
         spline_run<YG>(s, ay.w, res);
       }
       const int xx = ox + c;
       const bool xin = xx >= ax.lo && xx <= ax.hi;
+      if (xx < X) {
 #pragma unroll
-      for (int k = 0; k < YG; ++k) {
-        int yy = oy + y0 + k;
-        bool inside = xin && yy >= ay.lo && yy <= ay.hi;
-        float v = inside ? fminf(fmaxf(res[k], 0.f), 65535.f) : 0.f;
-        otile[(y0 + k) * AP_RP + c] = (unsigned)v;   // truncation toward zero
-      }
-    }
-    __syncthreads();
-
-    // ---- store: 16 bytes per lane when the row pitch allows it
-    if (vec_ok && ox + AP_TX <= X) {
-      for (int i = tid; i < TY * (AP_TX / 8); i += 256) {
-        int r = i / (AP_TX / 8), sgm = i - r * (AP_TX / 8);
-        if (oy + r < Y) {
-          const unsigned* sp = otile + r * AP_RP + 8 * sgm;
-          u16x8 w8;
-#pragma unroll
-          for (int k = 0; k < 8; ++k) w8.v[k] = (uint16_t)sp[k];
-          store8(po + (size_t)(oy + r) * X + ox + 8 * sgm, w8);
+        for (int k = 0; k < YG; ++k) {
+          const int yy = oy + y0 + k;
+          const bool inside = xin && yy >= ay.lo && yy <= ay.hi;
+          const float v = inside ? fminf(fmaxf(res[k], 0.f), 65535.f) : 0.f;
+#ifdef IAP_AP_NOSTORE
+          if (yy < Y && v == 12345.5f) po[(size_t)yy * X + xx] = (uint16_t)(unsigned)v;
+#else
+          if (yy < Y) po[(size_t)yy * X + xx] = (uint16_t)(unsigned)v;   // truncation toward zero
+#endif
         }
       }
-    } else {
-      for (int i = tid; i < TY * AP_TX; i += 256) {
-        int r = i / AP_TX, c = i - r * AP_TX;
-        if (oy + r < Y && ox + c < X) po[(size_t)(oy + r) * X + ox + c] = (uint16_t)otile[r * AP_RP + c];
-      }
     }
-    __syncthreads();   // the output tile aliases the input tile of the next iteration
+    AP_STAMP(5);
   }
+#ifdef IAP_AP_STAMPS
+  if (tid == 0)
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_ap_stamps[i], (unsigned long long)t_acc[i]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1199,7 +1232,6 @@ static int launch_apply(const uint16_t* in, uint16_t* out, long long n_frames, l
                         const double* shifts, hipStream_t st) {
   int TY = 32;
   if (const char* e = getenv("IAP_APPLY_TY")) TY = atoi(e) == 64 ? 64 : 32;
-  const int vec_ok = (X % 8 == 0) && (((long long)Y * X) % 8 == 0) && aligned16(in) && aligned16(out);
   const int tiles_x = (X + AP_TX - 1) / AP_TX;
   // each workgroup walks `ntx` tiles along x, prefetching the next tile while it filters this one
   int ntx = 16;
@@ -1215,10 +1247,10 @@ static int launch_apply(const uint16_t* in, uint16_t* out, long long n_frames, l
     ProfScope ps_(K_APPLY, st);
     if (TY == 64)
       hipLaunchKernelGGL(apply_shift_kernel<64>, grid, dim3(256), 0, st, in + (size_t)f0 * ppf * Y * X,
-                         out + (size_t)f0 * ppf * Y * X, ppf, Y, X, shifts + 2 * f0, vec_ok, ntx);
+                         out + (size_t)f0 * ppf * Y * X, ppf, Y, X, shifts + 2 * f0, ntx);
     else
       hipLaunchKernelGGL(apply_shift_kernel<32>, grid, dim3(256), 0, st, in + (size_t)f0 * ppf * Y * X,
-                         out + (size_t)f0 * ppf * Y * X, ppf, Y, X, shifts + 2 * f0, vec_ok, ntx);
+                         out + (size_t)f0 * ppf * Y * X, ppf, Y, X, shifts + 2 * f0, ntx);
   }
   IAP_LAUNCH_CHECK();
   return IAP_OK;
