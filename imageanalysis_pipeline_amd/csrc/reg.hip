@@ -791,8 +791,11 @@ __device__ __forceinline__ void spline_run(const float* s, const float (&w)[4], 
     out[k] = fmaf(w[0], cp[k], fmaf(w[1], cp[k + 1], fmaf(w[2], cp[k + 2], w[3] * cp[k + 3])));
 }
 
+#ifndef AP_MIN_WAVES
+#define AP_MIN_WAVES 4
+#endif
 template <int TY>
-__global__ __launch_bounds__(256) void apply_shift_kernel(const uint16_t* __restrict__ in,
+__global__ __launch_bounds__(256, AP_MIN_WAVES) void apply_shift_kernel(const uint16_t* __restrict__ in,
                                                           uint16_t* __restrict__ out, long long planes_per_frame,
                                                           int Y, int X, const double* __restrict__ shifts, int ntx) {
   constexpr int TH = TY + 2 * AP_R + 3;                  // staged rows
@@ -804,7 +807,8 @@ __global__ __launch_bounds__(256) void apply_shift_kernel(const uint16_t* __rest
   constexpr int NVEC = TH * (AP_TW / 8);                 // 16-byte vectors per staged tile
   constexpr int NV = (NVEC + 255) / 256;                 // ... per thread
   static_assert((AP_TX / AP_XG - 1) * AP_XG + XS <= AP_TW, "x runs stay inside the staged columns");
-  __shared__ __align__(16) uint16_t tile[TH * AP_PITCH]; // source tile; column 0 = first sample needed
+  static_assert(AP_PITCH % 8 == 0, "rows are whole 16-byte vectors");
+  __shared__ u32x4 tile[TH * (AP_PITCH / 8)];            // source tile as u16x8 vectors; column 0 = first sample needed
   __shared__ __align__(16) float colp[AP_TX * CP];       // after the x pass, transposed: [column][row]
   __shared__ AxisParams pay, pax;
   const int tid = threadIdx.x;
@@ -845,7 +849,7 @@ __global__ __launch_bounds__(256) void apply_shift_kernel(const uint16_t* __rest
     if (yy < 0 || yy >= Y) yy = rows_valid ? reflect101_idx(yy, Y) : 0;
     rowoff[jv] = (size_t)yy * X;
     v8[jv] = 8 * v;
-    lds_off[jv] = r * AP_PITCH + 8 * v;
+    lds_off[jv] = r * (AP_PITCH / 8) + v;
   }
   u32x4 q[NV];  // kept opaque so that the loads stay in flight until the tile is staged
   auto geom = [&](int tx, int& first, bool& valid) {
@@ -878,7 +882,7 @@ __global__ __launch_bounds__(256) void apply_shift_kernel(const uint16_t* __rest
           for (int k = 0; k < 8; ++k) e[k] = p[rowoff[jv] + reflect101_idx(col0 + k, X)];
           w8 = (u32x4){e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
         }
-        *reinterpret_cast<u32x4*>(tile + lds_off[jv]) = w8;
+        tile[lds_off[jv]] = w8;
       }
     }
   };
@@ -921,13 +925,16 @@ __global__ __launch_bounds__(256) void apply_shift_kernel(const uint16_t* __rest
     // ---- x pass: TH rows x 4 runs of 16 outputs; lanes run along rows; result stored transposed
     for (int i = tid; i < TH * (AP_TX / AP_XG); i += 256) {
       const int m = i / TH, r = i - m * TH;
-      const u16x8* t = reinterpret_cast<const u16x8*>(tile + r * AP_PITCH + AP_XG * m);
+      const u32x4* t = tile + r * (AP_PITCH / 8) + (AP_XG / 8) * m;
       float s[XS];
 #pragma unroll
       for (int k = 0; k < XS / 8; ++k) {
-        const u16x8 v8r = t[k];
+        const u32x4 v8r = t[k];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s[8 * k + e] = (float)v8r.v[e];
+        for (int e = 0; e < 4; ++e) {
+          s[8 * k + 2 * e] = (float)(v8r[e] & 0xffffu);
+          s[8 * k + 2 * e + 1] = (float)(v8r[e] >> 16);
+        }
       }
       float res[AP_XG];
       if (ax.whole) {

@@ -1,5 +1,7 @@
 // Development micro-benchmark for apply_shift_kernel (per-phase cycle counters of thread 0).
+#ifndef NO_STAMPS
 #define IAP_AP_STAMPS 1
+#endif
 #include "../imageanalysis_pipeline_amd/csrc/reg.hip"
 using namespace iap;
 int main(int argc, char** argv) {
@@ -15,13 +17,17 @@ int main(int argc, char** argv) {
   dim3 grid((X / 64 + ntx - 1) / ntx, Y / TY, n);
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   for (int k = 0; k < 4; ++k) {
-    unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_ap_stamps), z, sizeof(z));
+    unsigned long long z[8] = {0};
+#ifdef IAP_AP_STAMPS
+    hipMemcpyToSymbol(HIP_SYMBOL(g_ap_stamps), z, sizeof(z));
+#endif
     hipEventRecord(a);
-    if (TY == 64) hipLaunchKernelGGL(apply_shift_kernel<64>, grid, dim3(256), 0, 0, in, out, 1LL, Y, X, sh, ntx);
-    else hipLaunchKernelGGL(apply_shift_kernel<32>, grid, dim3(256), 0, 0, in, out, 1LL, Y, X, sh, ntx);
+    hipLaunchKernelGGL(apply_shift_kernel<32>, grid, dim3(256), 0, 0, in, out, 1LL, Y, X, sh, ntx);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
+#ifdef IAP_AP_STAMPS
     hipMemcpyFromSymbol(z, HIP_SYMBOL(g_ap_stamps), sizeof(z));
+#endif
     double tiles = (double)n * (Y / TY) * (X / 64);
     printf("%.2f us/plane | cycles per tile: prologue %.0f syncA %.0f xpass %.0f syncB %.0f stage %.0f ypass+store %.0f\n", ms * 1e3 / n,
            z[0] / tiles, z[1] / tiles, z[2] / tiles, z[3] / tiles, z[4] / tiles, z[5] / tiles);
