@@ -252,7 +252,10 @@ def main():
         prof = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(prof):
             try:
-                roof["traffic"] = json.load(open(prof)).get(dname)
+                tr = json.load(open(prof)).get(dname)
+                if tr:  # measured beforehand with rocprofv3 --pmc (separate passes), see profiles/
+                    roof["traffic"] = tr.get("hbm_bytes_per_launch")
+                    roof["traffic_detail"] = tr
             except Exception:
                 pass
         if args.stage_report and rank == 0:

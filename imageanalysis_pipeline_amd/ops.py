@@ -117,8 +117,9 @@ _ws_cache: dict = {}
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only scratch tensor per device (the library itself never allocates)."""
-    key = str(device)
+    """Grow-only scratch tensor per device and stream (the library itself never allocates; calls
+    on different streams may overlap, so they must not share scratch)."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = None
