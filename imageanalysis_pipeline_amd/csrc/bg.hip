@@ -31,9 +31,13 @@ constexpr int HIST_WORDS = HIST_FINE + HIST_COARSE;
 
 enum { SMO_MODE_IMAGE = 0, SMO_MODE_HIST = 1 };
 
+// Four neighbouring pixels of one lane as two packed pairs (px 0,1 and px 2,3): element-wise
+// arithmetic on them is one v_pk_*_f32 per pair (the march kernel is VALU-issue bound).
+typedef float v2f __attribute__((ext_vector_type(2)));
 struct f4 {
-  float v[4];
+  v2f lo, hi;
 };
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
 // raw (unconverted) row segment of one lane: 4 pixels
 template <typename T> struct Raw4;
@@ -56,15 +60,14 @@ __device__ __forceinline__ Raw4<float> load_raw4<float>(const float* __restrict_
 }
 __device__ __forceinline__ f4 to_f4(const Raw4<uint16_t>& r) {
   f4 o;
-  o.v[0] = (float)(r.w.x & 0xffffu);
-  o.v[1] = (float)(r.w.x >> 16);
-  o.v[2] = (float)(r.w.y & 0xffffu);
-  o.v[3] = (float)(r.w.y >> 16);
+  o.lo = (v2f){(float)(r.w.x & 0xffffu), (float)(r.w.x >> 16)};
+  o.hi = (v2f){(float)(r.w.y & 0xffffu), (float)(r.w.y >> 16)};
   return o;
 }
 __device__ __forceinline__ f4 to_f4(const Raw4<float>& r) {
   f4 o;
-  o.v[0] = r.w.x; o.v[1] = r.w.y; o.v[2] = r.w.z; o.v[3] = r.w.w;
+  o.lo = (v2f){r.w.x, r.w.y};
+  o.hi = (v2f){r.w.z, r.w.w};
   return o;
 }
 __device__ __forceinline__ uint2 as_u2(const Raw4<uint16_t>& r) { return r.w; }
@@ -74,12 +77,13 @@ __device__ __forceinline__ f4 load_row4(const T* __restrict__ row, int x, bool o
   return to_f4(load_raw4<T>(row, x, ok));
 }
 
-// value of lane-1 / lane+1 through DPP wave shifts (one VALU move each, no LDS traffic)
+// value of lane-1 / lane+1 through DPP wave shifts (one VALU move each, no LDS traffic); the end
+// lanes, which have no neighbour, receive 0 (they are halo lanes whose results are not used)
 __device__ __forceinline__ float from_left(float x) {   // lane i receives lane i-1
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x138, 0xf, 0xf, false));  // wave_shr:1
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138, 0xf, 0xf, true));  // wave_shr:1, lane 0 <- 0
 }
 __device__ __forceinline__ float from_right(float x) {  // lane i receives lane i+1
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x130, 0xf, 0xf, false));  // wave_shl:1
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130, 0xf, 0xf, true));  // wave_shl:1, lane 63 <- 0
 }
 
 struct SmoGeom {
@@ -93,61 +97,66 @@ struct SmoLane {
   bool edge_l, edge_r;  // this lane holds image column 0 (as its col 0) / X-1 (as its col 3)
   bool mir_l, mir_r;    // lane 1 of the leftmost / lane 62 of the rightmost strip: mirrored halo
   bool edge_strip;      // wave-uniform: leftmost or rightmost strip
+  float fx_l, fx_r;     // 2 where the x difference of col 0 / col 3 is one-sided, else 1
 };
 
 // One row of horizontally 7-summed unit-gradient components from image rows v-1, v, v+1.
 // first_row / last_row (wave-uniform): np.gradient's one-sided differences at the plane edge.
+// Gradients are kept at twice np.gradient's scale (central difference without the 1/2, one-sided
+// differences doubled): the factor cancels exactly in the normalisation.
 __device__ __forceinline__ void smo_row(const f4& A, const f4& B, const f4& Cn, bool first_row, bool last_row,
                                         const SmoLane& ln, f4& hy, f4& hx) {
-  const float bl = from_left(B.v[3]);
-  const float br = from_right(B.v[0]);
-  const float ys = (first_row || last_row) ? 1.0f : 0.5f;
-  float ny[4], nx[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float up = first_row ? B.v[i] : A.v[i];
-    const float dn = last_row ? B.v[i] : Cn.v[i];
-    const float gy = ys * (dn - up);
-    float l = (i == 0) ? bl : B.v[i - 1];
-    float r = (i == 3) ? br : B.v[i + 1];
-    float xs = 0.5f;
-    if (i == 0 && ln.edge_l) { l = B.v[0]; xs = 1.0f; }
-    if (i == 3 && ln.edge_r) { r = B.v[3]; xs = 1.0f; }
-    const float gx = xs * (r - l);
-    const float n2 = gy * gy + gx * gx;
-    const float inv = n2 > 0.f ? __builtin_amdgcn_rsqf(n2) : 0.f;
-    ny[i] = gy * inv;
-    nx[i] = gx * inv;
+  const float bl = from_left(B.hi.y);
+  const float br = from_right(B.lo.x);
+  v2f gy_lo, gy_hi;
+  if (first_row || last_row) {  // wave-uniform
+    const f4& up = first_row ? B : A;
+    const f4& dn = last_row ? B : Cn;
+    gy_lo = 2.0f * (dn.lo - up.lo);
+    gy_hi = 2.0f * (dn.hi - up.hi);
+  } else {
+    gy_lo = Cn.lo - A.lo;
+    gy_hi = Cn.hi - A.hi;
   }
+  // x neighbours: l = (bl, B0, B1, B2), r = (B1, B2, B3, br); one-sided (doubled) at the image edge
+  const float gx0 = ln.fx_l * (B.lo.y - (ln.edge_l ? B.lo.x : bl));
+  const float gx3 = ln.fx_r * ((ln.edge_r ? B.hi.y : br) - B.hi.x);
+  const v2f gx_lo = {gx0, B.hi.x - B.lo.x};
+  const v2f gx_hi = {B.hi.y - B.lo.y, gx3};
+  const v2f n2_lo = pk_fma(gx_lo, gx_lo, gy_lo * gy_lo);
+  const v2f n2_hi = pk_fma(gx_hi, gx_hi, gy_hi * gy_hi);
+  // zero gradient -> 0 * rsq(tiny) = 0 (non-zero n2 is >= 1 on integer pixels, far above the floor)
+  const v2f inv_lo = {__builtin_amdgcn_rsqf(fmaxf(n2_lo.x, 1e-30f)), __builtin_amdgcn_rsqf(fmaxf(n2_lo.y, 1e-30f))};
+  const v2f inv_hi = {__builtin_amdgcn_rsqf(fmaxf(n2_hi.x, 1e-30f)), __builtin_amdgcn_rsqf(fmaxf(n2_hi.y, 1e-30f))};
+  const v2f ny_lo = gy_lo * inv_lo, ny_hi = gy_hi * inv_hi;
+  const v2f nx_lo = gx_lo * inv_lo, nx_hi = gx_hi * inv_hi;
   // neighbours' columns: left lane's cols 1..3, right lane's cols 0..2
-  float ly1 = from_left(ny[1]), ly2 = from_left(ny[2]), ly3 = from_left(ny[3]);
-  float lx1 = from_left(nx[1]), lx2 = from_left(nx[2]), lx3 = from_left(nx[3]);
-  float ry0 = from_right(ny[0]), ry1 = from_right(ny[1]), ry2 = from_right(ny[2]);
-  float rx0 = from_right(nx[0]), rx1 = from_right(nx[1]), rx2 = from_right(nx[2]);
+  float ly1 = from_left(ny_lo.y), ly2 = from_left(ny_hi.x), ly3 = from_left(ny_hi.y);
+  float lx1 = from_left(nx_lo.y), lx2 = from_left(nx_hi.x), lx3 = from_left(nx_hi.y);
+  float ry0 = from_right(ny_lo.x), ry1 = from_right(ny_lo.y), ry2 = from_right(ny_hi.x);
+  float rx0 = from_right(nx_lo.x), rx1 = from_right(nx_lo.y), rx2 = from_right(nx_hi.x);
   if (ln.edge_strip) {  // wave-uniform: only the first and the last strip of a row mirror a halo
     if (ln.mir_l) {  // columns -3,-2,-1 mirror columns 2,1,0 (scipy 'reflect')
-      ly1 = ny[2]; ly2 = ny[1]; ly3 = ny[0];
-      lx1 = nx[2]; lx2 = nx[1]; lx3 = nx[0];
+      ly1 = ny_hi.x; ly2 = ny_lo.y; ly3 = ny_lo.x;
+      lx1 = nx_hi.x; lx2 = nx_lo.y; lx3 = nx_lo.x;
     }
     if (ln.mir_r) {  // columns X,X+1,X+2 mirror X-1,X-2,X-3
-      ry0 = ny[3]; ry1 = ny[2]; ry2 = ny[1];
-      rx0 = nx[3]; rx1 = nx[2]; rx2 = nx[1];
+      ry0 = ny_hi.y; ry1 = ny_hi.x; ry2 = ny_lo.y;
+      rx0 = nx_hi.y; rx1 = nx_hi.x; rx2 = nx_lo.y;
     }
   }
-  float sy = (ny[0] + ny[1]) + (ny[2] + ny[3]);
-  float sx = (nx[0] + nx[1]) + (nx[2] + nx[3]);
-  hy.v[0] = sy + ((ly1 + ly2) + ly3);
-  hy.v[1] = sy + ((ly2 + ly3) + ry0);
-  hy.v[2] = sy + (ly3 + (ry0 + ry1));
-  hy.v[3] = sy + ((ry0 + ry1) + ry2);
-  hx.v[0] = sx + ((lx1 + lx2) + lx3);
-  hx.v[1] = sx + ((lx2 + lx3) + rx0);
-  hx.v[2] = sx + (lx3 + (rx0 + rx1));
-  hx.v[3] = sx + ((rx0 + rx1) + rx2);
+  // 7-sums: out0 = own + l1+l2+l3, out1 = own + l2+l3+r0, out2 = own + l3+r0+r1, out3 = own + r0+r1+r2
+  const v2f s2y = ny_lo + ny_hi, s2x = nx_lo + nx_hi;
+  const float sy = s2y.x + s2y.y, sx = s2x.x + s2x.y;
+  const float ty = ly2 + ly3, uy = ry0 + ry1, tx = lx2 + lx3, ux = rx0 + rx1;
+  hy.lo = ((v2f){ly1, ry0} + (v2f){ty, ty}) + (v2f){sy, sy};
+  hy.hi = ((v2f){ly3, ry2} + (v2f){uy, uy}) + (v2f){sy, sy};
+  hx.lo = ((v2f){lx1, rx0} + (v2f){tx, tx}) + (v2f){sx, sx};
+  hx.hi = ((v2f){lx3, rx2} + (v2f){ux, ux}) + (v2f){sx, sx};
 }
 
 template <typename T, int MODE>
-__global__ __launch_bounds__(SMO_WAVES * 64) void smo_march_kernel(
+__global__ __launch_bounds__(SMO_WAVES * 64, 3) void smo_march_kernel(
     const T* __restrict__ src, const uint16_t* __restrict__ orig, float* __restrict__ smo_out,
     unsigned* __restrict__ hist, SmoGeom g, float thr2 /* (threshold*49)^2 */, float inv_area) {
   __shared__ unsigned lds_fine[SMO_WAVES][SMO_WIN];
@@ -192,8 +201,8 @@ __global__ __launch_bounds__(SMO_WAVES * 64) void smo_march_kernel(
     if (win_base > (unsigned)(HIST_FINE - SMO_WIN)) win_base = HIST_FINE - SMO_WIN;
   }
 
-  float ry[7][4], rx[7][4];  // vertical ring, statically indexed
-  float vy[4], vx[4];        // running vertical 7-row sums (re-summed exactly every 7th row)
+  v2f ry[7][2], rx[7][2];    // vertical ring (pixel pairs), statically indexed
+  v2f vy[2], vx[2];          // running vertical 7-row sums (re-summed exactly every 7th row)
   const int vbase = y0 - 3;
   const int vfirst = top ? 0 : vbase;
   SmoLane ln;
@@ -202,6 +211,8 @@ __global__ __launch_bounds__(SMO_WAVES * 64) void smo_march_kernel(
   ln.mir_l = left_strip && lane == 1;
   ln.mir_r = right_strip && lane == 62;
   ln.edge_strip = left_strip || right_strip;
+  ln.fx_l = ln.edge_l ? 2.0f : 1.0f;
+  ln.fx_r = ln.edge_r ? 2.0f : 1.0f;
   // rows v-1, v, v+1 of the row being computed; rows v+2 and v+3 are in flight, unconverted
   f4 A = load_row4<T>(p + (size_t)max(vfirst - 1, 0) * X, xl, col_ok);
   f4 B = load_row4<T>(p + (size_t)vfirst * X, xl, col_ok);
@@ -232,15 +243,13 @@ __global__ __launch_bounds__(SMO_WAVES * 64) void smo_march_kernel(
       if (RAWRING) rawr[((PH) + 2) % 7] = as_u2(Dn);                      \
       Dn = En;                                                                                       \
       En = load_raw4<T>(p + (size_t)min((VROW) + 4, Y - 1) * X, xl, col_ok);                            \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
-        ry[PH][i] = hy_.v[i];                                                                        \
-        rx[PH][i] = hx_.v[i];                                                                        \
-      }                                                                                              \
+      ry[PH][0] = hy_.lo; ry[PH][1] = hy_.hi;                                                        \
+      rx[PH][0] = hx_.lo; rx[PH][1] = hx_.hi;                                                        \
     } else {                                                                                         \
       const int j_ = (VROW) - Y;                                                                        \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
-        float ty_ = j_ == 0 ? ry[((PH) + 6) % 7][i] : (j_ == 1 ? ry[((PH) + 4) % 7][i] : ry[((PH) + 2) % 7][i]); \
-        float tx_ = j_ == 0 ? rx[((PH) + 6) % 7][i] : (j_ == 1 ? rx[((PH) + 4) % 7][i] : rx[((PH) + 2) % 7][i]); \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                \
+        v2f ty_ = j_ == 0 ? ry[((PH) + 6) % 7][i] : (j_ == 1 ? ry[((PH) + 4) % 7][i] : ry[((PH) + 2) % 7][i]); \
+        v2f tx_ = j_ == 0 ? rx[((PH) + 6) % 7][i] : (j_ == 1 ? rx[((PH) + 4) % 7][i] : rx[((PH) + 2) % 7][i]); \
         ry[PH][i] = ty_;                                                                             \
         rx[PH][i] = tx_;                                                                             \
       }                                                                                              \
@@ -248,7 +257,7 @@ __global__ __launch_bounds__(SMO_WAVES * 64) void smo_march_kernel(
   } while (0)
 
 #define SMO_RESUM()                                                                                    \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
     vy[i] = ((ry[0][i] + ry[1][i]) + (ry[2][i] + ry[3][i])) + ((ry[4][i] + ry[5][i]) + ry[6][i]);      \
     vx[i] = ((rx[0][i] + rx[1][i]) + (rx[2][i] + rx[3][i])) + ((rx[4][i] + rx[5][i]) + rx[6][i]);      \
   }
@@ -258,14 +267,14 @@ __global__ __launch_bounds__(SMO_WAVES * 64) void smo_march_kernel(
   for (int s = 0; s < 7; ++s) {
     if (top && s < 3) {  // rows -3..-1: mirrored copies, filled below
 #pragma unroll
-      for (int i = 0; i < 4; ++i) ry[s][i] = rx[s][i] = 0.f;
+      for (int i = 0; i < 2; ++i) ry[s][i] = rx[s][i] = (v2f){0.f, 0.f};
       continue;
     }
     SMO_FILL(s, vbase + s);
   }
   if (top) {  // virtual rows -3,-2,-1 = rows 2,1,0
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2; ++i) {
       ry[0][i] = ry[5][i]; rx[0][i] = rx[5][i];
       ry[1][i] = ry[4][i]; rx[1][i] = rx[4][i];
       ry[2][i] = ry[3][i]; rx[2][i] = rx[3][i];
@@ -277,19 +286,22 @@ __global__ __launch_bounds__(SMO_WAVES * 64) void smo_march_kernel(
   auto emit = [&](int oy, const uint2& rawrow) {
     if (MODE == SMO_MODE_IMAGE) {
       if (lane_own) {
+        const v2f m0 = pk_fma(vx[0], vx[0], vy[0] * vy[0]), m1 = pk_fma(vx[1], vx[1], vy[1] * vy[1]);
         float4 o;
-        o.x = sqrtf(vy[0] * vy[0] + vx[0] * vx[0]) * inv_area;
-        o.y = sqrtf(vy[1] * vy[1] + vx[1] * vx[1]) * inv_area;
-        o.z = sqrtf(vy[2] * vy[2] + vx[2] * vx[2]) * inv_area;
-        o.w = sqrtf(vy[3] * vy[3] + vx[3] * vx[3]) * inv_area;
+        o.x = sqrtf(m0.x) * inv_area;
+        o.y = sqrtf(m0.y) * inv_area;
+        o.z = sqrtf(m1.x) * inv_area;
+        o.w = sqrtf(m1.y) * inv_area;
         *reinterpret_cast<float4*>(smo_out + ((size_t)plane * Y + oy) * X + xl) = o;
       }
     } else {
+      const v2f m0 = pk_fma(vx[0], vx[0], vy[0] * vy[0]), m1 = pk_fma(vx[1], vx[1], vy[1] * vy[1]);
+      const float mag2[4] = {m0.x, m0.y, m1.x, m1.y};
       bool bgp[4];
       bool any = false;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        bgp[i] = lane_own && (vy[i] * vy[i] + vx[i] * vx[i] < thr2);
+        bgp[i] = lane_own && (mag2[i] < thr2);
         any |= bgp[i];
       }
       if (any) {  // ~5 % of the background pixels pass: most lanes skip the whole block
@@ -317,8 +329,8 @@ __global__ __launch_bounds__(SMO_WAVES * 64) void smo_march_kernel(
   // SMO_STEP(ph, FILL): replace slot ph, update the running sums, emit.
 #define SMO_STEP(PH, FILLER)                                                                           \
   do {                                                                                               \
-    float oy_[4], ox_[4];                                                                            \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
+    v2f oy_[2], ox_[2];                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                  \
       oy_[i] = ry[PH][i];                                                                            \
       ox_[i] = rx[PH][i];                                                                            \
     }                                                                                                \
@@ -326,7 +338,7 @@ __global__ __launch_bounds__(SMO_WAVES * 64) void smo_march_kernel(
     if ((PH) == 0) {                                                                                 \
       SMO_RESUM();                                                                                   \
     } else {                                                                                         \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                \
         vy[i] += ry[PH][i] - oy_[i];                                                                 \
         vx[i] += rx[PH][i] - ox_[i];                                                                 \
       }                                                                                              \
@@ -345,10 +357,8 @@ __global__ __launch_bounds__(SMO_WAVES * 64) void smo_march_kernel(
     if (RAWRING) rawr[((PH) + 2) % 7] = as_u2(Dn);                        \
     Dn = En;                                                                                         \
     En = load_raw4<T>(p + (size_t)((VROW) + 4) * X, xl, col_ok);                                      \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                  \
-      ry[PH][i] = hy_.v[i];                                                                          \
-      rx[PH][i] = hx_.v[i];                                                                          \
-    }                                                                                                \
+    ry[PH][0] = hy_.lo; ry[PH][1] = hy_.hi;                                                          \
+    rx[PH][0] = hx_.lo; rx[PH][1] = hx_.hi;                                                          \
   } while (0)
 
   int oy = y0 + 1;

@@ -10,12 +10,14 @@
 //   K3 rows_c2r_argmax  inverse row FFT + wave-shuffle / LDS arg-max (correlation surface is
 //                    never written to HBM)
 //   K4 coarse_finish    arg-max over the per-workgroup partials -> signed integer shift
-//   K5 upsample_partial matrix-DFT of P on a 15x15 grid of 0.1 px offsets (partials per chunk)
+//   K5 upsample_tables / upsample_partial  matrix-DFT of P on a 15x15 grid of 0.1 px offsets,
+//                    +-m symmetric form, per-chunk partials (the Nyquist column rides in the
+//                    table kernel)
 //   K6 upsample_finish  sum partials, arg-max, parabolic vertex -> (dy, dx) as f64
-// Apply: apply_shift_kernel -- separable 24-tap cardinal cubic B-spline FIR (the exact
-// prefilter+interpolation of scipy.ndimage.shift(order=3), truncated at 0.268^12) on LDS
-// tiles; mirror boundary, zero outside, clip, truncate to u16.  Integer shifts degenerate to
-// a delta kernel and are therefore exact copies.
+// Apply: apply_shift_kernel -- separable cubic B-spline shift = scipy.ndimage.shift(order=3):
+// mirror-boundary prefilter as two one-multiply recursions started from 12 explicit taps
+// (truncation 0.268^12), then the 4-tap evaluation; LDS tiles walked along x; zero outside,
+// clip, truncate to u16.  An axis with an integer shift bypasses the filter: exact copies.
 #include <math.h>
 #include <stdlib.h>
 #include "common.h"
@@ -1237,8 +1239,7 @@ static int launch_mip(const uint16_t* in, long long in_stride, uint16_t* out, lo
 
 static int launch_apply(const uint16_t* in, uint16_t* out, long long n_frames, long long ppf, int Y, int X,
                         const double* shifts, hipStream_t st) {
-  int TY = 32;
-  if (const char* e = getenv("IAP_APPLY_TY")) TY = atoi(e) == 64 ? 64 : 32;
+  constexpr int TY = 32;
   const int tiles_x = (X + AP_TX - 1) / AP_TX;
   // each workgroup walks `ntx` tiles along x, prefetching the next tile while it filters this one
   int ntx = 16;
@@ -1252,12 +1253,8 @@ static int launch_apply(const uint16_t* in, uint16_t* out, long long n_frames, l
     long long nf = n_frames - f0 < fpc ? n_frames - f0 : fpc;
     grid.z = (unsigned)(nf * ppf);
     ProfScope ps_(K_APPLY, st);
-    if (TY == 64)
-      hipLaunchKernelGGL(apply_shift_kernel<64>, grid, dim3(256), 0, st, in + (size_t)f0 * ppf * Y * X,
-                         out + (size_t)f0 * ppf * Y * X, ppf, Y, X, shifts + 2 * f0, ntx);
-    else
-      hipLaunchKernelGGL(apply_shift_kernel<32>, grid, dim3(256), 0, st, in + (size_t)f0 * ppf * Y * X,
-                         out + (size_t)f0 * ppf * Y * X, ppf, Y, X, shifts + 2 * f0, ntx);
+    hipLaunchKernelGGL(apply_shift_kernel<TY>, grid, dim3(256), 0, st, in + (size_t)f0 * ppf * Y * X,
+                       out + (size_t)f0 * ppf * Y * X, ppf, Y, X, shifts + 2 * f0, ntx);
   }
   IAP_LAUNCH_CHECK();
   return IAP_OK;
