@@ -208,9 +208,12 @@ __global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_r2c_kernel
 }
 
 // K2 ---------------------------------------------------------------------------------------
-// mode 0: forward column FFT in place (reference spectrum).
-// mode 1: forward FFT, P = G * conj(F) * scale (DC = 0, optional /|P|), store P to R (if R),
-//         inverse FFT, store back to F in place.
+// mode 0: forward column FFT of the reference; the spectrum is written to R in TILE-MAJOR order
+//         (the TC columns x N rows of a workgroup form one contiguous block), because every
+//         moving frame re-reads it tile by tile: contiguous 16-byte-per-lane reads instead of
+//         32-byte row pieces.
+// mode 1: forward FFT, P = G * conj(F) * scale (DC = 0, optional /|P|) with G = Gref (tile-major),
+//         store P to R (row-major, if R), inverse FFT, store back to F in place.
 template <int N>
 __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_kernel(
     cf* __restrict__ F, long long F_stride, const cf* __restrict__ Gref, cf* __restrict__ R, long long R_stride,
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_kerne
       int idx = tid + m * NTH;
       int cc = idx % Gm::TC, u = idx / Gm::TC;
       cf g = lds_c[cc * Gm::CS + padi(u)];
-      cf f = Gref[(size_t)u * Wp + v0 + cc];
+      cf f = Gref[(size_t)v0 * N + idx];
       cf p = make_float2((f.x * g.x + f.y * g.y) * scale, (f.y * g.x - f.x * g.y) * scale);
       if (normalize) {
         float m2 = p.x * p.x + p.y * p.y;
@@ -252,6 +255,15 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_kerne
     }
     __syncthreads();
     fft_lds<N, +1, Gm::CE>(s, j, tw);
+  }
+  if (mode == 0) {
+#pragma unroll 4
+    for (int m = 0; m < Gm::CE; ++m) {
+      int idx = tid + m * NTH;
+      int cc = idx % Gm::TC, u = idx / Gm::TC;
+      R[(size_t)v0 * N + idx] = lds_c[cc * Gm::CS + padi(u)];
+    }
+    return;
   }
 #pragma unroll 4
   for (int m = 0; m < Gm::CE; ++m) {
@@ -1166,11 +1178,12 @@ static int reg_init_tables(const RegPlan& p, RegWs& w, hipStream_t st) {
   return IAP_OK;
 }
 
-// full 2-D spectrum of the reference plane into w.refspec
+// full 2-D spectrum of the reference plane into w.refspec (tile-major, see cols_kernel); the row
+// pass goes through the first frame slot of w.F, which is free between batches
 static int reg_ref_spectrum(const RegPlan& p, RegWs& w, const void* ref, int kind, float in_scale, hipStream_t st) {
-  int rc = launch_rows_r2c(p, ref, kind, 0, in_scale, w.refspec, 0, 1, w.tw_x, st);
+  int rc = launch_rows_r2c(p, ref, kind, 0, in_scale, w.F, 0, 1, w.tw_x, st);
   if (rc) return rc;
-  return launch_cols(p, w.refspec, 0, nullptr, nullptr, 0, 1, w.tw_y, 0, 0, st);
+  return launch_cols(p, w.F, 0, nullptr, w.refspec, 0, 1, w.tw_y, 0, 0, st);
 }
 
 // shifts for n moving planes (n <= w.batch) against w.refspec

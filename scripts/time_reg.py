@@ -5,12 +5,13 @@ from imageanalysis_pipeline_amd import ops, _lib
 dev = torch.device("cuda:0")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+up = (sys.argv[3] != '0') if len(sys.argv) > 3 else True
 x = torch.randint(0, 3000, (n, 2048, 2048), dtype=torch.int32, device=dev).to(torch.uint16)
 lib = _lib.load()
-ops.estimate_shifts(x[0], x, batch=batch); torch.cuda.synchronize()
+ops.estimate_shifts(x[0], x, batch=batch, upsample=up); torch.cuda.synchronize()
 lib.iap_prof_enable(1)
 t0 = time.perf_counter()
-for _ in range(3): ops.estimate_shifts(x[0], x, batch=batch)
+for _ in range(3): ops.estimate_shifts(x[0], x, batch=batch, upsample=up)
 torch.cuda.synchronize()
 print(f"estimate n={n} batch={batch}: {(time.perf_counter() - t0) / 3 * 1e3 / n * 1e3:.1f} us/frame")
 for k in range(lib.iap_prof_kernel_count()):
