@@ -1,0 +1,127 @@
+"""Whole hot path (background-subtract -> register -> per-label measure) through the C-ABI against the
+oracle, on reduced versions of BASELINE.json's configurations (C1 two-channel, C3 z-stack, C5 dense
+labels) and the three reference-frame modes of utility.py:332-413.
+
+Bars: integer drift -> everything bit-exact; sub-pixel drift -> shifts within
+0.01 px, warped pixels within 1 count, hence per-label means within 1 count and areas/centroids exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from imageanalysis_pipeline_amd import ops, synth
+from oracle import ref_path as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_gpu(dev, st, lab, thr, reg_ref, upsample):
+    d = ops.to_device_u16(st, dev)
+    bg, _, _ = ops.bg_smo(d, thr)
+    reg, sh = ops.im_reg(bg, 0, reg_ref, upsample=upsample)
+    tables = ops.measure_labels(reg, ops.to_device_u16(lab, dev))
+    torch.cuda.synchronize()
+    return ops.to_numpy_u16(reg), sh.cpu().numpy(), tables
+
+
+def _labels(t, z, y, x, n):
+    lab2 = synth.make_labels(y, x, n)
+    return np.broadcast_to(lab2[None, None], (t, z, y, x)).copy()
+
+
+@pytest.mark.parametrize("reg_ref", ["first", "mean", "previous"])
+def test_c1_like_integer_drift_bit_exact(dev, reg_ref):
+    t, c, y, x = 6, 2, 256, 256
+    st, _ = synth.make_stack(t, c, 1, y, x, n_cells=20, integer_drift=True)
+    lab = _labels(t, 1, y, x, 20)
+    thr = O.smo_threshold((y, x))
+    reg, sh, tab = _run_gpu(dev, st, lab, thr, reg_ref, upsample=False)
+    ereg, esh, etab = O.run_path_opts(st, lab, thr, reg_ref=reg_ref, upsample=False)
+    assert np.array_equal(sh, esh)
+    assert np.array_equal(reg, ereg)
+    for g, e in zip(tab, etab):
+        assert np.array_equal(g["ids"], e["ids"])
+        assert np.array_equal(g["area"], e["area"])
+        assert np.array_equal(g["mean"].view(np.uint64), e["mean"].view(np.uint64))
+        assert np.array_equal(g["centroid_rne"], e["centroid_rne"])
+
+
+def test_c1_like_subpixel_drift_within_tolerance(dev):
+    t, c, y, x = 5, 2, 256, 256
+    st, _ = synth.make_stack(t, c, 1, y, x, n_cells=20, integer_drift=False)
+    lab = _labels(t, 1, y, x, 20)
+    thr = O.smo_threshold((y, x))
+    reg, sh, tab = _run_gpu(dev, st, lab, thr, "first", upsample=True)
+    ereg, esh, etab = O.run_path_opts(st, lab, thr, reg_ref="first", upsample=True)
+    assert np.abs(sh - esh).max() <= 0.01            # sub-pixel tolerance of north_star
+    # the warp is evaluated with each side's own shift: compare where the shifts agree to 1e-4 px
+    # pixel-wise (<= 1 count), and the tables everywhere (<= 1 count in the mean)
+    close = np.abs(sh - esh).max(axis=1) <= 1e-4
+    if close.any():
+        d = np.abs(reg[close].astype(np.int64) - ereg[close].astype(np.int64))
+        assert d.max() <= 1
+    for g, e in zip(tab, etab):
+        assert np.array_equal(g["ids"], e["ids"])
+        assert np.array_equal(g["area"], e["area"])
+        assert np.array_equal(g["centroid_rne"], e["centroid_rne"])
+        assert np.abs(g["mean"] - e["mean"]).max() <= 1.0
+
+
+def test_c3_like_zstack_mip_registration(dev):
+    t, c, z, y, x = 3, 2, 5, 128, 256
+    st, _ = synth.make_stack(t, c, z, y, x, n_cells=10, integer_drift=True)
+    lab = _labels(t, z, y, x, 10)
+    thr = O.smo_threshold((y, x))
+    reg, sh, tab = _run_gpu(dev, st, lab, thr, "first", upsample=False)
+    ereg, esh, etab = O.run_path_opts(st, lab, thr, reg_ref="first", upsample=False)
+    assert np.array_equal(sh, esh)
+    assert np.array_equal(reg, ereg)
+    for g, e in zip(tab, etab):            # volumetric labels: (z, y, x) centroids
+        assert np.array_equal(g["ids"], e["ids"])
+        assert np.array_equal(g["area"], e["area"])
+        assert np.array_equal(g["mean"].view(np.uint64), e["mean"].view(np.uint64))
+        assert np.array_equal(g["centroid_rne"], e["centroid_rne"])
+
+
+def test_c5_like_dense_labels_measure_only(dev):
+    y = x = 1024
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 65536, size=(2, 1, y, x), dtype=np.uint16)      # (T, C, Y, X)
+    lab = np.stack([synth.make_dense_labels(y, x)[None]] * 2)             # (T, Z=1, Y, X)
+    tab = ops.measure_labels(ops.to_device_u16(img[:, :, None], dev), ops.to_device_u16(lab, dev))
+    for f in range(2):
+        e = O.measure_labels(img[f], lab[f, 0])
+        g = tab[f]
+        assert len(g["ids"]) > 150                                            # the grid really is dense
+        assert np.array_equal(g["ids"], e["ids"])
+        assert np.array_equal(g["area"], e["area"])
+        assert np.array_equal(g["mean"].view(np.uint64), e["mean"].view(np.uint64))
+        assert np.array_equal(g["centroid_rne"], e["centroid_rne"])
+
+
+def test_full_size_checksum_properties(dev):
+    """C2 plane size: properties that need no oracle.  (i) the label areas partition the frame;
+    (ii) sum(area * mean) equals the integer sum of the labelled pixels; (iii) an integer-shifted
+    frame registers back onto the reference bit-exactly inside the overlap."""
+    y = x = 2048
+    st, _ = synth.make_stack(2, 1, 1, y, x, n_cells=60, integer_drift=True, seed=3)
+    lab = _labels(2, 1, y, x, 60)
+    d = ops.to_device_u16(st, dev)
+    tab = ops.measure_labels(d, ops.to_device_u16(lab, dev))
+    for f in range(2):
+        g = tab[f]
+        fg = lab[f, 0] != 0
+        assert int(g["area"].sum()) == int(fg.sum())
+        total = int(st[f, 0, 0][fg].astype(np.uint64).sum())
+        assert abs(float((g["area"] * g["mean"][:, 0]).sum()) - total) <= 1e-6 * total
+    reg, sh = ops.im_reg(d, 0, "first", upsample=False)
+    sh = sh.cpu().numpy()
+    assert np.array_equal(sh, np.rint(sh))
+    dy, dx = int(sh[1, 0]), int(sh[1, 1])
+    r = ops.to_numpy_u16(reg)[1, 0, 0]
+    src = st[1, 0, 0]
+    ys = slice(max(dy, 0), y + min(dy, 0))
+    xs = slice(max(dx, 0), x + min(dx, 0))
+    ys0 = slice(max(-dy, 0), y + min(-dy, 0))
+    xs0 = slice(max(-dx, 0), x + min(-dx, 0))
+    assert np.array_equal(r[ys, xs], src[ys0, xs0])      # out[y, x] = in[y - dy, x - dx]
