@@ -180,11 +180,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP library is the only implementation)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU.  IAP_BENCH_BACKEND=gloo is a rehearsal hook for boxes with fewer GPUs than
+    # ranks (ranks then share devices and the table gather goes through host memory).
+    backend = os.environ.get("IAP_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     t, c, z, y, x, n_cells = WORKLOADS[args.workload]
     if args.frames:
@@ -196,7 +203,8 @@ def main():
     def one_step():
         tables = path.step()
         if world > 1:
-            return gather_rows(pack_rows(tables, rank), world)
+            rows = pack_rows(tables, rank)
+            return gather_rows(rows if backend == "nccl" else rows.cpu(), world)
         return tables
 
     for _ in range(args.warmup):
@@ -217,7 +225,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     ktimes = collect_kernel_times() if timing else {}
