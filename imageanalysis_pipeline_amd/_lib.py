@@ -30,6 +30,9 @@ SIGNATURES = {
     "iap_measure_labels_u16": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "iap_measure_finalize": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "iap_max_u16": (_i32, [_vp, _i64, _vp, _vp]),
+    "iap_tiff_probe": (_i32, [C.c_char_p] + [C.POINTER(_i32)] * 6),
+    "iap_tiff_read_u16": (_i32, [C.POINTER(C.c_char_p), _i64, _vp, _i32, _i32, _i32]),
+    "iap_tiff_write_u16": (_i32, [C.POINTER(C.c_char_p), _i64, _vp, _i32, _i32, _i32]),
     "iap_prof_enable": (None, [_i32]),
     "iap_prof_kernel_count": (_i32, []),
     "iap_prof_kernel_name": (C.c_char_p, [_i32]),

@@ -23,7 +23,7 @@ import pandas as pd
 import torch
 
 from . import ops
-from .tiffio import imread, imwrite
+from .tiffio import imread, imwrite, read_planes, write_planes
 
 
 def _device():
@@ -31,6 +31,19 @@ def _device():
         from ._lib import IapError
         raise IapError("imageanalysis_pipeline_amd needs an MI355X: there is no CPU fallback")
     return torch.device("cuda", torch.cuda.current_device())
+
+
+def _read_u16_planes(paths):
+    """n plane files -> (n, Y, X) uint16: the batched native reader (csrc/tiffio.hip), or the generic
+    per-file reader when a file is not a stripped, uncompressed 16-bit unsigned classic TIFF."""
+    try:
+        return read_planes(paths)
+    except ValueError:
+        return np.stack([imread(p) for p in paths]).astype(np.uint16)
+
+
+def _write_u16_planes(paths, planes):
+    write_planes(paths, np.ascontiguousarray(planes, dtype=np.uint16))
 
 
 class Utility:
@@ -78,14 +91,20 @@ class Utility:
             chan_lst = exp_para["channel_list"]
         frame_range = input_range if input_range else range(exp_para["t"])
         idx = Utility._folder_index(imgFold_path)
-        exp_list = []
-        for chan in chan_lst:
-            chan_list = []
-            for frame in frame_range:
-                names = [v for (p, f, z), v in sorted(idx.items(), key=lambda kv: kv[0][2])
-                         if p.startswith(chan) and f == frame]
-                chan_list.append([imread(join(sep, imgFold_path + sep, n)) for n in names])
-            exp_list.append(chan_list)
+        names = [[[v for (p, f, z), v in sorted(idx.items(), key=lambda kv: kv[0][2])
+                   if p.startswith(chan) and f == frame] for frame in frame_range] for chan in chan_lst]
+        flat = [join(sep, imgFold_path + sep, n) for chan in names for fr in chan for n in fr]
+        nz = {len(fr) for chan in names for fr in chan}
+        exp_list = None
+        if flat and len(nz) == 1:
+            # batched native read (csrc/tiffio.hip): one pass of a thread pool into one buffer
+            try:
+                planes = read_planes(flat)
+                exp_list = planes.reshape(len(chan_lst), len(frame_range), nz.pop(), *planes.shape[1:])
+            except ValueError:
+                exp_list = None  # compressed / tiled / other sample type: generic reader below
+        if exp_list is None:
+            exp_list = [[[imread(join(sep, imgFold_path + sep, n)) for n in fr] for fr in chan] for chan in names]
         if len(chan_lst) == 1:
             return np.squeeze(np.stack(exp_list))
         return np.moveaxis(np.squeeze(np.stack(exp_list)), [0], [-1])
@@ -134,25 +153,23 @@ class Utility:
         chans = channels if channels is not None else exp_para["channel_list"]
         t, z = exp_para["t"], exp_para["z"]
         idx = Utility._folder_index(fold_path)
-        first = imread(join(sep, fold_path + sep, next(iter(idx.values()))))
-        y, x = first.shape
-        stack = np.empty((t, len(chans), z, y, x), dtype=np.uint16)
-        for ci, chan in enumerate(chans):
-            for f in range(t):
+        paths = []
+        for f in range(t):
+            for chan in chans:
                 for k in range(z):
                     name = idx.get((prefix_of(chan), f, k))
                     if name is None:
                         raise FileNotFoundError(f"{fold_path}: missing plane {prefix_of(chan)} f={f + 1} z={k + 1}")
-                    stack[f, ci, k] = imread(join(sep, fold_path + sep, name))
-        return stack
+                    paths.append(join(sep, fold_path + sep, name))
+        planes = _read_u16_planes(paths)
+        return planes.reshape(t, len(chans), z, *planes.shape[1:])
 
     @staticmethod
     def _write_folder_stack(fold_path, stack, channels):
         t, c, z = stack.shape[:3]
-        for ci, chan in enumerate(channels):
-            for f in range(t):
-                for k in range(z):
-                    imwrite(join(sep, fold_path + sep, Utility._plane_name(chan, f, k)), stack[f, ci, k])
+        paths = [join(sep, fold_path + sep, Utility._plane_name(chan, f, k))
+                 for f in range(t) for chan in channels for k in range(z)]
+        _write_u16_planes(paths, np.asarray(stack).reshape(t * c * z, *stack.shape[3:]))
 
     # ------------------------------------------------------------------ background (utility.py:175-270)
     @staticmethod
@@ -165,13 +182,12 @@ class Utility:
         # every .tif of the folder, whatever its channel (utility.py:255-256), in one resident batch
         names = [f for f in sorted(listdir(imgFold_path)) if f.endswith(".tif")]
         if names:
-            planes = np.stack([imread(join(sep, imgFold_path + sep, f)) for f in names]).astype(np.uint16)
+            paths = [join(sep, imgFold_path + sep, f) for f in names]
+            planes = _read_u16_planes(paths)
             thr = ops.smo_threshold(planes.shape[-2:], sigma=sigma, size=size, seed=seed, device=dev)
             d = ops.to_device_u16(planes, dev)
             out, _, _ = ops.bg_smo(d, thr, sigma=sigma, size=size, out=d)     # in place, as the reference
-            res = ops.to_numpy_u16(out)
-            for f, plane in zip(names, res):
-                imwrite(join(sep, imgFold_path + sep, f), plane)
+            _write_u16_planes(paths, ops.to_numpy_u16(out))
         exp_prop["fct_inputs"]["smo_bg_sub"] = {"imgFold_path": imgFold_path, "smo_sigma": sigma, "smo_size": size}
         exp_prop["img_preProcess"]["bg_sub"] = "Auto"
         Utility.save_exp_prop(exp_path=exp_path, exp_prop=exp_prop)
@@ -265,10 +281,9 @@ class Utility:
             names = [f for f in sorted(listdir(imgFold_path)) if f.endswith(".tif")]
             if names:
                 dev = _device()
-                planes = np.stack([imread(join(sep, imgFold_path + sep, f)) for f in names]).astype(np.uint16)
+                planes = _read_u16_planes([join(sep, imgFold_path + sep, f) for f in names])
                 res = ops.to_numpy_u16(ops.gauss_blur(ops.to_device_u16(planes, dev), blur_kernel, blur_sigma))
-                for f, plane in zip(names, res):
-                    imwrite(join(sep, blur_img_path + sep, f), plane)
+                _write_u16_planes([join(sep, blur_img_path + sep, f) for f in names], res)
             exp_prop["fct_inputs"]["blur_img"] = {"imgFold_path": imgFold_path, "blur_kernel": blur_kernel,
                                                   "blur_sigma": blur_sigma, "blur_ow": blur_ow}
             exp_prop["img_preProcess"]["blur"] = True

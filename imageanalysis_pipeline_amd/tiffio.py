@@ -2,12 +2,14 @@
 single-page, uncompressed, 16-bit (or 8/32-bit) grayscale, as written by
 ``tifffile.imwrite(path, plane.astype(np.uint16))`` (utility.py:166, 264, 355, 616).
 
-File I/O stays in the reference (north_star); this module only exists so that the folder-level
-shim (pipeline.py) works where ``tifffile`` is not installed.  When ``tifffile`` is importable it
-is used instead.
+``imread`` / ``imwrite`` are the single-plane calls of the reference (tifffile when importable, a
+pure-Python baseline reader otherwise).  ``read_planes`` / ``write_planes`` are the batched native
+path (csrc/tiffio.hip): a thread pool moves whole plane sequences between files
+and one pinned host buffer, which load_stack then copies to the GPU in one async transfer.
 """
 from __future__ import annotations
 
+import os
 import struct
 
 import numpy as np
@@ -16,6 +18,64 @@ try:  # pragma: no cover - depends on the environment
     import tifffile as _tf
 except Exception:  # noqa: BLE001
     _tf = None
+
+IO_THREADS = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+
+
+def _path_array(paths):
+    import ctypes as C
+    arr = (C.c_char_p * len(paths))()
+    arr[:] = [os.fsencode(p) for p in paths]
+    return arr
+
+
+def probe(path: str):
+    """(Y, X, bits, sample_format, compression, samples) of the first directory of a classic TIFF."""
+    import ctypes as C
+    from . import _lib
+    v = [C.c_int() for _ in range(6)]
+    _lib.check(_lib.load().iap_tiff_probe(os.fsencode(path), *[C.byref(x) for x in v]), "iap_tiff_probe")
+    return tuple(x.value for x in v)
+
+
+def read_planes(paths, shape=None, pinned: bool = False, threads: int | None = None):
+    """n uint16 planes of identical shape from n TIFF files -> (n, Y, X) array (a pinned torch tensor
+    when ``pinned``).  Raises ValueError naming the file for anything but stripped, uncompressed,
+    single-sample 16-bit unsigned classic TIFF (callers fall back to ``imread`` per file)."""
+    from . import _lib
+    paths = list(paths)
+    if not paths:
+        raise ValueError("read_planes: no files")
+    if shape is None:
+        y, x, bits, sfmt, comp, spp = probe(paths[0])
+    else:
+        y, x = shape
+    lib = _lib.load()
+    if pinned:
+        import torch
+        out = torch.empty((len(paths), y, x), dtype=torch.uint16, pin_memory=torch.cuda.is_available())
+        ptr = out.data_ptr()
+    else:
+        out = np.empty((len(paths), y, x), dtype=np.uint16)
+        ptr = out.ctypes.data
+    _lib.check(lib.iap_tiff_read_u16(_path_array(paths), len(paths), ptr, y, x, threads or IO_THREADS),
+               "iap_tiff_read_u16")
+    return out
+
+
+def write_planes(paths, planes, threads: int | None = None) -> None:
+    """(n, Y, X) uint16 planes -> n little-endian single-strip TIFF files."""
+    from . import _lib
+    paths = list(paths)
+    a = planes
+    if not isinstance(a, np.ndarray):  # torch tensor on the host
+        a = a.view(getattr(__import__("torch"), "int16")).numpy().view(np.uint16)
+    a = np.ascontiguousarray(a, dtype=np.uint16)
+    if a.ndim != 3 or a.shape[0] != len(paths):
+        raise ValueError("write_planes: planes must be (n, Y, X) with one path per plane")
+    _lib.check(_lib.load().iap_tiff_write_u16(_path_array(paths), len(paths), a.ctypes.data, a.shape[1], a.shape[2],
+                                              threads or IO_THREADS), "iap_tiff_write_u16")
+
 
 _TYPES = {1: ("B", 1), 2: ("c", 1), 3: ("H", 2), 4: ("I", 4), 5: ("II", 8), 16: ("Q", 8)}
 

@@ -132,6 +132,20 @@ int iap_measure_finalize(const uint64_t* acc, int64_t T, int L, int C,
 /* Max label value of a u16 label stack of n elements -> device u32 (zeroed by the call). */
 int iap_max_u16(const uint16_t* labels, int64_t n, uint32_t* out, void* stream);
 
+/* ------------------------------------------------------------------ plane files (host) -- */
+
+/* The step on either side of the hot path: the reference keeps every
+ * (channel, frame, z) plane in its own baseline TIFF (tifffile.imwrite(plane.astype(uint16)),
+ * utility.py:155-166, 264, 355, 616) and re-reads the stack file by file (utility.py:487-524
+ * load_stack, :558-595 load_mask).  These calls move n planes of Y x X u16 between n files and
+ * one contiguous HOST buffer (pinned for a following async copy) with a pool of `threads`
+ * threads; no device work, no stream.  Read accepts classic TIFF, II or MM, one 16-bit unsigned
+ * sample, uncompressed, stripped; anything else returns IAP_E_UNSUPPORTED naming the file (the
+ * shim then uses its generic reader).  Write produces little-endian single-strip files. */
+int iap_tiff_probe(const char* path, int* Y, int* X, int* bits, int* sample_format, int* compression, int* samples);
+int iap_tiff_read_u16(const char* const* paths, int64_t n, uint16_t* dst, int Y, int X, int threads);
+int iap_tiff_write_u16(const char* const* paths, int64_t n, const uint16_t* src, int Y, int X, int threads);
+
 /* ------------------------------------------------------------------ instrumentation ---- */
 
 /* Optional per-kernel timing with HIP events recorded on the launch stream (no counterpart in

@@ -1,0 +1,113 @@
+"""Batched native TIFF plane I/O (csrc/tiffio.hip, SURVEY 8f rank 1: the step either side of the hot
+path; reference: tifffile.imwrite/imread loops of utility.py:155-166, 264, 487-524).  Host code only:
+these tests run without a GPU.  Cross-checked against the independent pure-Python reader/writer of
+imageanalysis_pipeline_amd.tiffio and against hand-assembled files."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from imageanalysis_pipeline_amd import tiffio
+
+
+def _paths(tmp_path, n):
+    return [str(tmp_path / f"GFP_s01_f{i + 1:04d}_z0001.tif") for i in range(n)]
+
+
+def test_write_then_read_round_trip_many_threads(tmp_path):
+    rng = np.random.default_rng(0)
+    planes = rng.integers(0, 65536, size=(37, 45, 70), dtype=np.uint16)
+    paths = _paths(tmp_path, len(planes))
+    tiffio.write_planes(paths, planes, threads=5)
+    back = tiffio.read_planes(paths, threads=7)
+    assert back.dtype == np.uint16 and np.array_equal(back, planes)
+    # every file is also a plain baseline TIFF for an independent reader
+    for p, a in zip(paths[:5], planes[:5]):
+        assert np.array_equal(tiffio.imread(p), a)
+    assert tiffio.probe(paths[0]) == (45, 70, 16, 1, 1, 1)
+
+
+def test_reads_files_of_the_python_writer(tmp_path):
+    rng = np.random.default_rng(1)
+    planes = rng.integers(0, 65536, size=(4, 33, 17), dtype=np.uint16)     # odd width
+    paths = _paths(tmp_path, 4)
+    for p, a in zip(paths, planes):
+        tiffio.imwrite(p, a)
+    assert np.array_equal(tiffio.read_planes(paths), planes)
+
+
+def _hand_made(path, a, big_endian, rows_per_strip):
+    """classic TIFF with several strips, offsets stored after the directory, chosen byte order"""
+    bo = ">" if big_endian else "<"
+    h, w = a.shape
+    strips = [a[r:r + rows_per_strip].astype(bo + "u2").tobytes() for r in range(0, h, rows_per_strip)]
+    n = len(strips)
+    data_off = 8
+    offs, pos = [], data_off
+    for s in strips:
+        offs.append(pos)
+        pos += len(s)
+    ifd = pos + (pos & 1)
+    nent = 9
+    arr_off = ifd + 2 + 12 * nent + 4
+    ent = [(256, 3, 1, w), (257, 3, 1, h), (258, 3, 1, 16), (259, 3, 1, 1), (262, 3, 1, 1),
+           (273, 4, n, arr_off if n > 1 else offs[0]), (277, 3, 1, 1), (278, 3, 1, rows_per_strip),
+           (279, 4, n, arr_off + 4 * n if n > 1 else len(strips[0]))]
+    out = bytearray((b"MM" if big_endian else b"II") + struct.pack(bo + "HI", 42, ifd))
+    for s in strips:
+        out += s
+    out += b"\0" * (ifd - len(out))
+    out += struct.pack(bo + "H", nent)
+    for tag, typ, cnt, val in ent:
+        out += struct.pack(bo + "HHI", tag, typ, cnt)
+        out += struct.pack(bo + "HH", val, 0) if (typ == 3 and cnt == 1) else struct.pack(bo + "I", val)
+    out += struct.pack(bo + "I", 0)
+    if n > 1:
+        out += struct.pack(bo + "I" * n, *offs) + struct.pack(bo + "I" * n, *[len(s) for s in strips])
+    with open(path, "wb") as fh:
+        fh.write(bytes(out))
+
+
+@pytest.mark.parametrize("big_endian", [False, True])
+@pytest.mark.parametrize("rows_per_strip", [1, 7, 64])
+def test_strips_and_byte_orders(tmp_path, big_endian, rows_per_strip):
+    rng = np.random.default_rng(2)
+    a = rng.integers(0, 65536, size=(20, 31), dtype=np.uint16)
+    p = str(tmp_path / "x.tif")
+    _hand_made(p, a, big_endian, rows_per_strip)
+    assert np.array_equal(tiffio.read_planes([p])[0], a)
+
+
+def test_errors_name_the_file(tmp_path):
+    a = np.arange(12, dtype=np.uint16).reshape(3, 4)
+    good, other = str(tmp_path / "a.tif"), str(tmp_path / "b.tif")
+    tiffio.write_planes([good], a[None])
+    tiffio.write_planes([other], np.zeros((1, 5, 4), np.uint16))
+    with pytest.raises(ValueError, match="b.tif.*5x4.*expected 3x4"):
+        tiffio.read_planes([good, other])
+    with pytest.raises(ValueError, match="missing.tif"):
+        tiffio.read_planes([good, str(tmp_path / "missing.tif")], shape=(3, 4))
+    junk = str(tmp_path / "junk.tif")
+    with open(junk, "wb") as fh:
+        fh.write(b"not a tiff at all")
+    with pytest.raises(ValueError, match="junk.tif.*not a TIFF"):
+        tiffio.read_planes([junk], shape=(3, 4))
+    # 8-bit planes are legal TIFF but not what the batched reader takes: reported as unsupported
+    eight = str(tmp_path / "eight.tif")
+    tiffio.imwrite(eight, np.zeros((3, 4), np.uint8))
+    with pytest.raises(ValueError, match="eight.tif.*16-bit"):
+        tiffio.read_planes([eight], shape=(3, 4))
+    with pytest.raises(ValueError):
+        tiffio.write_planes([good], np.zeros((2, 3, 4), np.uint16))       # one path, two planes
+    with pytest.raises(ValueError, match="no_such_dir"):
+        tiffio.write_planes([str(tmp_path / "no_such_dir" / "x.tif")], a[None])
+
+
+def test_shim_falls_back_for_other_sample_types(tmp_path):
+    from imageanalysis_pipeline_amd import pipeline
+    paths = [str(tmp_path / f"p{i}.tif") for i in range(3)]
+    for i, p in enumerate(paths):
+        tiffio.imwrite(p, np.full((4, 6), i, np.uint8))
+    got = pipeline._read_u16_planes(paths)
+    assert got.dtype == np.uint16 and got.shape == (3, 4, 6) and [int(g[0, 0]) for g in got] == [0, 1, 2]
