@@ -143,6 +143,22 @@ def collect_kernel_times():
     return out
 
 
+def stream_copy_ceiling(dev, nbytes=1 << 30):
+    """Measured device copy rate (read + write bytes per second): the practical HBM ceiling that SURVEY 8(d)
+    asks to report beside the 8 TB/s datasheet peak.  torch's copy kernel is only the yardstick here."""
+    a = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * 5 / (e0.elapsed_time(e1) / 1e3) / 1e9
+
+
 def cpu_baseline(y, x, c, n_cells, budget_frames=6):
     """The oracle (numpy restatement of the reference CPU path) on a bounded sample of the workload:
     `budget_frames` frames x C channels of the same plane size, same stages."""
@@ -287,6 +303,8 @@ def main():
             out["stage_hbm_frac"] = {k: bpp[k] * px_step / (v / args.steps / 1e3) / HBM_PEAK for k, v in stages.items()}
         if roof:
             out["roofline"] = roof
+        if world == 1:
+            out["stream_copy_ceiling_GBps"] = stream_copy_ceiling(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(y, x, c, n_cells or 0)
         print(json.dumps(out))
