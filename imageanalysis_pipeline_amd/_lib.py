@@ -30,6 +30,12 @@ SIGNATURES = {
     "iap_measure_labels_u16": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "iap_measure_finalize": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "iap_max_u16": (_i32, [_vp, _i64, _vp, _vp]),
+    "iap_edt_ws_bytes": (_sz, [_i64, _i32, _i32]),
+    "iap_edt_sq_u16": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _sz, _vp]),
+    "iap_mask_chunks": (_i32, [_i32, _i32]),
+    "iap_mask_count_u16": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "iap_masked_gather_u16": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i64, _i32, _i32, _vp, _vp, C.c_double, _i64,
+                                     _vp, _vp, _vp]),
     "iap_tiff_probe": (_i32, [C.c_char_p] + [C.POINTER(_i32)] * 6),
     "iap_tiff_read_u16": (_i32, [C.POINTER(C.c_char_p), _i64, _vp, _i32, _i32, _i32]),
     "iap_tiff_write_u16": (_i32, [C.POINTER(C.c_char_p), _i64, _vp, _i32, _i32, _i32]),

@@ -312,3 +312,49 @@ def im_reg(stack: torch.Tensor, reg_channel: int = 0, reg_ref: str = "mean", ups
                                   REF_MODES[reg_ref], _reg_flags(upsample, normalize), shifts.data_ptr(),
                                   ws.data_ptr(), ws.numel(), _stream()), "iap_im_reg_u16")
     return out, shifts
+
+
+# ---------------------------------------------------------------- distance map / pixel table
+def edt_sq(mask: torch.Tensor) -> torch.Tensor:
+    """Squared Euclidean distance (int32, exact) of every pixel to the nearest non-zero pixel of ``mask``
+    (..., Y, X) u16: the square of ``mahotas.distance(~mask, 'euclidean')`` of utility.py:871-876."""
+    _need_cuda(mask)
+    _u16(mask)
+    n, y, x = _planes(mask)
+    lib = _lib.load()
+    ws = _workspace(lib.iap_edt_ws_bytes(n, y, x), mask.device)
+    out = torch.empty(mask.shape, dtype=torch.int32, device=mask.device)
+    _lib.check(lib.iap_edt_sq_u16(mask.data_ptr(), out.data_ptr(), n, y, x, ws.data_ptr(), ws.numel(), _stream()),
+               "iap_edt_sq_u16")
+    return out
+
+
+def masked_pixels(cell_mask: torch.Tensor, img: torch.Tensor, sq: torch.Tensor | None = None, pix_size: float = 1.0):
+    """analysis.py:276-283 for T frames: ``cell_mask`` (T, Y, X) u16, ``img`` (T, C, Y, X) u16, ``sq`` (T, Y, X)
+    int32 from :func:`edt_sq` (optional).  Returns (counts int64 (T,), dmap int32 (total,), values u16 (C, total));
+    the pixels of frame f occupy [counts[:f].sum(), counts[:f+1].sum()) in numpy boolean-indexing order."""
+    _need_cuda(cell_mask, img)
+    _u16(cell_mask)
+    _u16(img)
+    if cell_mask.ndim != 3 or img.ndim != 4 or img.shape[0] != cell_mask.shape[0] or img.shape[2:] != cell_mask.shape[1:]:
+        raise ValueError("masked_pixels: cell_mask (T, Y, X) and img (T, C, Y, X) must agree")
+    t, c, y, x = img.shape
+    if sq is not None:
+        _need_cuda(sq)
+        if sq.dtype != torch.int32 or sq.shape != cell_mask.shape:
+            raise ValueError("masked_pixels: sq must be int32 with the shape of cell_mask")
+    lib = _lib.load()
+    dev = cell_mask.device
+    nch = lib.iap_mask_chunks(y, x)
+    offs = torch.empty((t, nch), dtype=torch.int32, device=dev)
+    totals = torch.empty(t, dtype=torch.int64, device=dev)
+    _lib.check(lib.iap_mask_count_u16(cell_mask.data_ptr(), t, y, x, offs.data_ptr(), totals.data_ptr(), _stream()),
+               "iap_mask_count_u16")
+    base = torch.cumsum(totals, 0) - totals
+    total = int(totals.sum().item())
+    dmap = torch.empty(total, dtype=torch.int32, device=dev)
+    vals = torch.empty((c, total), dtype=torch.uint16, device=dev)
+    _lib.check(lib.iap_masked_gather_u16(cell_mask.data_ptr(), sq.data_ptr() if sq is not None else None, img.data_ptr(),
+                                         c * y * x, y * x, c, t, y, x, offs.data_ptr(), base.data_ptr(), float(pix_size),
+                                         total, dmap.data_ptr(), vals.data_ptr(), _stream()), "iap_masked_gather_u16")
+    return totals, dmap, vals

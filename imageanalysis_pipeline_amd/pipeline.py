@@ -290,6 +290,30 @@ class Utility:
             Utility.save_exp_prop(exp_path=exp_path, exp_prop=exp_prop)
         return exp_prop, blur_img_path
 
+    # ------------------------------------------------------------------ distance map (utility.py:829-876)
+    @staticmethod
+    def ref_mask(imgFold_path, maskLabel, ref_mask_ow=False):
+        """utility.py:829-868, loading branch: the reference masks drawn earlier (`Masks_<label>`).  Drawing
+        them (get_pre_wound GUI) is not part of this path and stays in the reference."""
+        if type(maskLabel) != str:
+            raise TypeError(f"Maskname cannot be of type {type(maskLabel)}. Only string is accepted")
+        exp_path = sep.join(imgFold_path.split(sep)[:-1])
+        mask_ref_path = join(sep, exp_path + sep, "Masks_" + maskLabel)
+        if isdir(mask_ref_path) and any(scandir(mask_ref_path)) and not ref_mask_ow:
+            print(f"-> Loading reference {'Masks_' + maskLabel} masks from Exp. {exp_path}")
+            return Utility.load_mask(maskFold_path=mask_ref_path, channel_seg=maskLabel, do_log=False)
+        raise NotImplementedError(f"no reference masks in {mask_ref_path}: draw them with the reference "
+                                  "pipeline (Utility.ref_mask); only existing masks are used here")
+
+    @staticmethod
+    def apply_dmap(mask_stack, frames):
+        """utility.py:871-876: mahotas.distance(~mask, 'euclidean') per frame -> float64 distances."""
+        m = np.asarray(mask_stack)
+        planes = m[None] if frames == 1 else m
+        sq = ops.edt_sq(ops.to_device_u16((planes != 0).astype(np.uint16), _device()))
+        dist = np.sqrt(sq.cpu().numpy().astype(np.float64))
+        return dist[0] if frames == 1 else dist
+
     @staticmethod
     def transfo_df(df, channel_list, stim_time=None, start_baseline=0, posCont_time=None, signal_type="linear"):
         """Table post-processing (ratios, deltaF, outliers: utility.py:924-1046) is out of the hot path and
@@ -451,3 +475,49 @@ class Analysis(Utility):
         else:
             print(f"---> Centroids are already extracted for {maskFold}")
             self.df_analysis = pd.read_csv(join(sep, self.exp_path + sep, "df_analysis.csv"))
+
+
+    # -- analysis.py:262-304 ---------------------------------------------------------------------
+    def pixel_distance(self, imgFold, maskFold, channel_seg=None, maskLabel="wound", pix_ana_ow=False,
+                       ref_mask_ow=False):
+        fi = self.exp_prop["fct_inputs"]
+        if "pixel_distance" not in fi or pix_ana_ow or not exists(join(sep, self.exp_path + sep, "df_pixel.csv")):
+            dev = _device()
+            img_path = join(sep, self.exp_path + sep, imgFold)
+            ref = np.asarray(Analysis.ref_mask(imgFold_path=img_path, maskLabel=maskLabel, ref_mask_ow=ref_mask_ow))
+            chan_seg = channel_seg if channel_seg else self.channel_seg
+            masks = np.asarray(Analysis.load_mask(maskFold_path=join(sep, self.exp_path + sep, maskFold),
+                                                  channel_seg=chan_seg))
+            t = self.frames
+            ref = ref.reshape(t, *ref.shape[-2:])
+            if masks.ndim != (2 if t == 1 else 3):
+                raise ValueError("pixel_distance needs 2-D cell masks per frame (volumetric masks cannot index the "
+                                 "maximum projection, analysis.py:281-282)")
+            masks = masks.reshape(t, *masks.shape[-2:])
+            exp_para = self.exp_prop["metadata"]
+            stack = ops.to_device_u16(Utility._read_folder_stack(img_path, exp_para), dev)      # (T, C, Z, Y, X)
+            if self.z_size > 1:                                                                   # np.amax over z
+                img = torch.stack([ops.mip(stack[:, c]) for c in range(stack.shape[1])], 1)
+            else:
+                img = stack[:, :, 0].contiguous()
+            sq = ops.edt_sq(ops.to_device_u16((ref != 0).astype(np.uint16), dev))
+            counts, dmap, vals = ops.masked_pixels(ops.to_device_u16(masks.astype(np.uint16), dev), img.contiguous(),
+                                                   sq, pix_size=float(self.pixSize))
+            counts = counts.cpu().numpy()
+            d = {"dmap": dmap.cpu().numpy().astype(int)}
+            v = ops.to_numpy_u16(vals)
+            for ci, chan in enumerate(self.channel_list):
+                d[chan] = v[ci].astype(float)
+            self.df_pixel = pd.DataFrame.from_dict(d)
+            self.df_pixel["time"] = np.repeat(np.asarray(self.ts, dtype=float), counts)
+            self.df_pixel["frame"] = np.repeat(np.arange(1, t + 1), counts)
+            self.df_pixel["tag"] = self.tag
+            self.df_pixel["exp"] = self._exp_name()
+            self.exp_prop["df_pixel"] = self.df_pixel
+            fi["pixel_distance"] = {"imgFold": imgFold, "maskFold": maskFold, "channel_seg": channel_seg,
+                                    "maskLabel": maskLabel}
+            Analysis.save_exp_prop(exp_path=self.exp_path, exp_prop=self.exp_prop)
+            self.df_pixel.to_csv(join(sep, self.exp_path + sep, "df_pixel.csv"), index=False)
+        else:
+            print(f"---> {maskLabel} mask was already created for pixel distance and value already extracted")
+            self.df_pixel = pd.read_csv(join(sep, self.exp_path + sep, "df_pixel.csv"))

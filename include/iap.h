@@ -132,6 +132,31 @@ int iap_measure_finalize(const uint64_t* acc, int64_t T, int L, int C,
 /* Max label value of a u16 label stack of n elements -> device u32 (zeroed by the call). */
 int iap_max_u16(const uint16_t* labels, int64_t n, uint32_t* out, void* stream);
 
+/* ------------------------------------------------------------------ distance map / pixel table */
+
+/* SURVEY 8f rank 2.  Utility.apply_dmap (utility.py:871-876): mahotas.distance(~mask, 'euclidean') per
+ * frame = Euclidean distance of every pixel to the nearest pixel of the reference (wound) mask.  Exact
+ * squared distances as int32 for n planes; mask != 0 marks the reference region (distance 0).  A plane
+ * without any mask pixel yields 30000^2 + ... (no finite answer exists).  ws: iap_edt_ws_bytes. */
+size_t iap_edt_ws_bytes(int64_t n, int Y, int X);
+int iap_edt_sq_u16(const uint16_t* mask, int32_t* sq_out, int64_t n, int Y, int X,
+                   void* ws, size_t ws_bytes, void* stream);
+
+/* Analysis.pixel_distance (analysis.py:276-283): per frame, for the pixels of a cell mask in numpy
+ * boolean-indexing (row-major) order: d = round(sqrt(sq) * pix_size) (np.round, half to even) and the
+ * pixel's value in every channel.  Two calls: iap_mask_count_u16 fills chunk_offsets
+ * (n x iap_mask_chunks(Y, X) int32, exclusive prefix per frame) and totals (int64 per frame); the caller
+ * turns totals into frame_base (exclusive prefix over frames, device int64[n]) and sizes the outputs:
+ * out_d int32[total], out_v u16[C][total].  img: frame f, channel c at img + f*img_frame_stride +
+ * c*img_chan_stride (elements).  sq may be NULL (out_d = 0) and out_d may be NULL. */
+int iap_mask_chunks(int Y, int X);
+int iap_mask_count_u16(const uint16_t* mask, int64_t n, int Y, int X, int32_t* chunk_offsets,
+                       int64_t* totals, void* stream);
+int iap_masked_gather_u16(const uint16_t* mask, const int32_t* sq, const uint16_t* img, int64_t img_frame_stride,
+                          int64_t img_chan_stride, int C, int64_t n, int Y, int X, const int32_t* chunk_offsets,
+                          const int64_t* frame_base, double pix_size, int64_t total, int32_t* out_d,
+                          uint16_t* out_v, void* stream);
+
 /* ------------------------------------------------------------------ plane files (host) -- */
 
 /* The step on either side of the hot path: the reference keeps every

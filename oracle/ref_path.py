@@ -493,3 +493,39 @@ def run_path_opts(stack: np.ndarray, labels: np.ndarray, threshold: float, reg_r
         else:
             tables.append(measure_labels(reg[f], labels[f]))
     return reg, shifts, tables
+
+
+# ---------------------------------------------------------------- distance map / pixel table
+def edt_sq(mask: np.ndarray) -> np.ndarray:
+    """Squared Euclidean distance of every pixel to the nearest non-zero pixel of a 2-D mask, exact int64:
+    the square of ``mahotas.distance(np.logical_not(mask), 'euclidean')`` (utility.py:871-876; mahotas is
+    absent here: pinned against scipy.ndimage.distance_transform_edt in tests/golden).  Separable: column
+    distances, then the exact minimum over columns of g[j]^2 + (x-j)^2."""
+    m = np.asarray(mask) != 0
+    y, x = m.shape
+    inf = 30000
+    g = np.full((y, x), inf, dtype=np.int64)
+    d = np.full(x, inf, dtype=np.int64)
+    for r in range(y):
+        d = np.where(m[r], 0, np.minimum(d + 1, inf))
+        g[r] = d
+    d = np.full(x, inf, dtype=np.int64)
+    for r in range(y - 1, -1, -1):
+        d = np.minimum(g[r], np.minimum(d + 1, inf))
+        g[r] = d
+    jj = np.arange(x, dtype=np.int64)
+    dx2 = (jj[:, None] - jj[None, :]) ** 2            # (x, j)
+    out = np.empty((y, x), dtype=np.int64)
+    for r in range(y):
+        out[r] = (g[r][None, :] ** 2 + dx2).min(axis=1)
+    return out
+
+
+def pixel_table(cell_mask: np.ndarray, img: np.ndarray, ref_mask: np.ndarray, pix_size: float):
+    """analysis.py:276-283 for one frame: (dmap int64, values (count, C)) of the pixels where cell_mask is
+    set, in boolean-indexing order; dmap = round(distance * pix_size) with np.round (half to even)."""
+    sel = np.asarray(cell_mask).astype(bool)
+    dist = np.sqrt(edt_sq(ref_mask).astype(np.float64))
+    dmap = np.round(dist[sel] * pix_size).astype(int)
+    vals = np.stack([np.asarray(img[c])[sel] for c in range(img.shape[0])], axis=1)
+    return dmap, vals

@@ -78,9 +78,22 @@ def golden_xcorr():
                         fine=np.array(fine))
 
 
+def golden_edt():
+    """scipy.ndimage.distance_transform_edt(~mask): the distance map of utility.py:871-876 (mahotas absent)."""
+    rng = np.random.default_rng(4)
+    masks = np.zeros((3, 48, 70), dtype=np.uint16)
+    masks[0, 10:20, 30:45] = 1                                   # a wound-like block
+    masks[1][rng.random((48, 70)) < 0.01] = 7                    # scattered seeds
+    masks[2, :, 0] = 1                                           # a full edge column
+    masks[2, 40, 60] = 1
+    dist = np.stack([ndi.distance_transform_edt(m == 0) for m in masks])
+    np.savez_compressed(os.path.join(HERE, "edt_scipy.npz"), masks=masks, dist=dist)
+
+
 if __name__ == "__main__":
     golden_regionprops()
     golden_shift()
     golden_smo()
     golden_xcorr()
     print("golden fixtures written to", HERE)
+    golden_edt()

@@ -86,3 +86,25 @@ def test_im_reg_stack_modes_recover_integer_drift():
         pass
     else:
         raise AssertionError("bad reg_ref must raise ValueError (utility.py:297-299)")
+
+
+def test_edt_vs_scipy():
+    """oracle edt_sq (separable exact integers) against scipy.ndimage.distance_transform_edt (golden)."""
+    g = np.load(os.path.join(G, "edt_scipy.npz"))
+    for m, d in zip(g["masks"], g["dist"]):
+        sq = O.edt_sq(m)
+        assert np.array_equal(np.sqrt(sq.astype(np.float64)), d)      # integer squares: sqrt is exact in f64
+
+
+def test_pixel_table_order_and_rounding():
+    ref = np.zeros((6, 8), np.uint16)
+    ref[0, 0] = 1
+    cell = np.zeros((6, 8), np.uint16)
+    cell[1, 2] = 3
+    cell[0, 5] = 9
+    cell[4, 0] = 1
+    img = np.arange(2 * 48, dtype=np.uint16).reshape(2, 6, 8)
+    dmap, vals = O.pixel_table(cell, img, ref, pix_size=0.5)
+    # row-major order: (0,5), (1,2), (4,0); distances 5, sqrt(5), 4 -> x0.5 -> 2.5, 1.118, 2.0 -> round-half-even
+    assert dmap.tolist() == [2, 1, 2]
+    assert vals.tolist() == [[5, 53], [10, 58], [32, 80]]

@@ -104,3 +104,44 @@ def test_man_bg_sub_and_blur(dev, tmp_path):
     assert path.endswith("Images_Blured") and prop["img_preProcess"]["blur"] is True
     assert np.array_equal(tiffio.imread(os.path.join(path, "GFP_f0001_z0001.tif")), O.gauss_blur(cur, (15, 15), 5))
     assert Utility.man_bg_sub(img, roi=None)["img_preProcess"]["bg_sub"] == "Manual"   # 'skip': untouched
+
+
+def test_pixel_distance_table(dev, tmp_path):
+    """Analysis.pixel_distance (analysis.py:262-304) on files: the literal numpy restatement per frame."""
+    t, c, y, x = 3, 2, 96, 128
+    chans = ("GFP", "RFP")
+    exp, _ = make_exp(tmp_path, t=t, c=c, y=y, x=x, chans=chans)
+    rng = np.random.default_rng(11)
+    stack = rng.integers(0, 65536, size=(t, c, 1, y, x), dtype=np.uint16)
+    _write_stack(exp, stack, chans)
+    prop = Utility.open_exp_prop(exp)
+    pix = float(prop["metadata"].get("pixel_microns") or 0.65)
+    prop["metadata"]["pixel_microns"] = pix
+    Utility.save_exp_prop(exp, prop)
+    wound = np.zeros((t, y, x), np.uint16)
+    for f in range(t):
+        wound[f, 30:50 - 3 * f, 40 + 5 * f:90] = 1                    # a closing wound
+    cells = np.stack([synth.make_labels(y, x, 8, seed=f) for f in range(t)])
+    for name, arr, key in (("Masks_wound", wound, "wound"), ("Masks_CP", cells, "GFP")):
+        d = os.path.join(exp, name)
+        os.makedirs(d)
+        Utility.save_mask(arr, d, batch=list(range(t)), z_size=1, frames=t, chan_seg=key)
+
+    a = Analysis(exp, "GFP")
+    a.pixel_distance(imgFold="Images", maskFold="Masks_CP", maskLabel="wound")
+    df = a.df_pixel
+    assert list(df.columns) == ["dmap", "GFP", "RFP", "time", "frame", "tag", "exp"]
+    pos = 0
+    for f in range(t):
+        ed, ev = O.pixel_table(cells[f], stack[f, :, 0], wound[f], pix)
+        part = df.iloc[pos:pos + len(ed)]
+        assert np.array_equal(part["dmap"].to_numpy(), ed)
+        assert np.array_equal(part[["GFP", "RFP"]].to_numpy(), ev.astype(float))
+        assert (part["frame"] == f + 1).all() and (part["time"] == a.ts[f]).all()
+        pos += len(ed)
+    assert pos == len(df)
+    assert os.path.exists(os.path.join(exp, "df_pixel.csv"))
+    assert Utility.open_exp_prop(exp)["fct_inputs"]["pixel_distance"]["maskLabel"] == "wound"
+    # apply_dmap keeps the reference's return shapes
+    assert Utility.apply_dmap(wound[0], 1).shape == (y, x)
+    assert np.array_equal(Utility.apply_dmap(wound, t)[1], np.sqrt(O.edt_sq(wound[1]).astype(float)))
