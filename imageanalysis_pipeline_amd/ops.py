@@ -358,3 +358,77 @@ def masked_pixels(cell_mask: torch.Tensor, img: torch.Tensor, sq: torch.Tensor |
                                          c * y * x, y * x, c, t, y, x, offs.data_ptr(), base.data_ptr(), float(pix_size),
                                          total, dmap.data_ptr(), vals.data_ptr(), _stream()), "iap_masked_gather_u16")
     return totals, dmap, vals
+
+
+# ---------------------------------------------------------------- mask stitching
+def label_overlap(a: torch.Tensor, b: torch.Tensor, na_max: int | None = None, nb_max: int | None = None) -> torch.Tensor:
+    """cellpose.metrics._label_overlap(a, b) for one pair of u16 label arrays of equal shape:
+    int64 (na_max+1, nb_max+1) with overlap[i, j] = #{a == i and b == j}."""
+    _need_cuda(a, b)
+    _u16(a)
+    _u16(b)
+    if a.shape != b.shape:
+        raise ValueError("label_overlap: shapes differ")
+    na = max_label(a) if na_max is None else int(na_max)
+    nb = max_label(b) if nb_max is None else int(nb_max)
+    out = torch.empty((na + 1, nb + 1), dtype=torch.int32, device=a.device)
+    _lib.check(_lib.load().iap_label_overlap_u16(a.data_ptr(), b.data_ptr(), 1, a.numel(), na, nb, out.data_ptr(),
+                                                 _stream()), "iap_label_overlap_u16")
+    return out.to(torch.int64)
+
+
+def iou_from_overlap(overlap) -> np.ndarray:
+    """cellpose.metrics._intersection_over_union from the overlap matrix (host, tiny)."""
+    ov = overlap.cpu().numpy().astype(np.float64) if isinstance(overlap, torch.Tensor) else np.asarray(overlap, np.float64)
+    n_pred = ov.sum(axis=0, keepdims=True)
+    n_true = ov.sum(axis=1, keepdims=True)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        iou = ov / (n_pred + n_true - ov)
+    iou[np.isnan(iou)] = 0.0
+    return iou
+
+
+def relabel(masks: torch.Tensor, lut: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """out = lut[masks] for u16 labels; ``lut`` (L,) for all planes or (n, L) per leading plane of ``masks``.
+    Every label present must be < L (checked)."""
+    _need_cuda(masks, lut)
+    _u16(masks)
+    _u16(lut)
+    if out is None:
+        out = torch.empty_like(masks)
+    if lut.ndim == 1:
+        n, px, stride = 1, masks.numel(), 0
+    else:
+        n, px, stride = masks.shape[0], masks[0].numel(), lut.shape[1]
+        if lut.shape[0] != n:
+            raise ValueError("relabel: one table per leading plane expected")
+    if max_label(masks) >= lut.shape[-1]:
+        raise ValueError("relabel: a label exceeds the lookup table")
+    _lib.check(_lib.load().iap_relabel_u16(masks.data_ptr(), out.data_ptr(), n, px, lut.data_ptr(), stride, _stream()),
+               "iap_relabel_u16")
+    return out
+
+
+def label_mode(masks: torch.Tensor) -> torch.Tensor:
+    """Master mask of utility.py:707-711: per pixel the most frequent non-zero label over the T leading
+    planes of ``masks`` (ties: smaller label; 0 if never labelled)."""
+    _need_cuda(masks)
+    _u16(masks)
+    t = masks.shape[0]
+    px = masks[0].numel()
+    out = torch.empty(masks.shape[1:], dtype=torch.uint16, device=masks.device)
+    nov = torch.zeros(1, dtype=torch.int32, device=masks.device)
+    _lib.check(_lib.load().iap_label_mode_u16(masks.data_ptr(), t, px, out.data_ptr(), nov.data_ptr(), _stream()),
+               "iap_label_mode_u16")
+    if int(nov.item()):  # pixels that saw more than 8 distinct labels: recount those few on the host
+        flat = out.view(-1).view(torch.int16)       # torch indexes int16, not uint16
+        idx = torch.nonzero(flat == -1).squeeze(1)
+        cols = masks.reshape(t, px).view(torch.int16)[:, idx].cpu().numpy().view(np.uint16)
+        fix = np.zeros(cols.shape[1], dtype=np.uint16)
+        for k in range(cols.shape[1]):
+            v = cols[:, k]
+            v = v[v != 0]
+            vals, cnt = np.unique(v, return_counts=True)
+            fix[k] = vals[np.argmax(cnt)] if len(vals) else 0
+        flat[idx] = torch.from_numpy(fix.view(np.int16)).to(masks.device)
+    return out

@@ -290,6 +290,49 @@ class Utility:
             Utility.save_exp_prop(exp_path=exp_path, exp_prop=exp_prop)
         return exp_prop, blur_img_path
 
+    # ------------------------------------------------------------------ mask stitching (utility.py:700-738)
+    @staticmethod
+    def _stitch_pass(d, ref_of, thr, new_ids):
+        """One round of IoU stitching on a device stack (T, Y, X) u16, in place: Cellpose's stitch3D loop
+        (new_ids) or the master-mask round of utility.py:717-737.  Overlap counting and relabelling run on
+        the GPU; the (labels x labels) IoU logic is the reference's numpy, on the host."""
+        mmax = ops.max_label(d[0])
+        empty = 0
+        for i in (range(1, d.shape[0]) if new_ids else range(d.shape[0])):
+            iou = ops.iou_from_overlap(ops.label_overlap(d[i], ref_of(i)))[1:, 1:]
+            if not iou.size and empty == 0:
+                mmax = ops.max_label(d[i])
+                continue
+            if not iou.size:
+                icount = ops.max_label(d[i])
+                istitch = np.arange(mmax + 1, mmax + icount + 1, 1, int)
+                mmax += icount
+            else:
+                iou[iou < thr] = 0.0
+                iou[iou < iou.max(axis=0)] = 0.0
+                istitch = iou.argmax(axis=1) + 1
+                ino = np.nonzero(iou.max(axis=1) == 0.0)[0]
+                if new_ids:
+                    istitch[ino] = np.arange(mmax + 1, mmax + len(ino) + 1, 1, int)
+                    mmax += len(ino)
+                else:
+                    istitch[ino] = 0
+                empty = 1
+            istitch = np.append(np.array(0), istitch)
+            if istitch.max() > 65535:
+                raise ValueError("stitching produced more than 65535 labels (masks are stored as uint16)")
+            ops.relabel(d[i], ops.to_device_u16(istitch.astype(np.uint16), d.device), out=d[i])
+
+    @staticmethod
+    def modif_stitch3D(masks, stitch_threshold):
+        """utility.py:700-738: Cellpose stitch3D, master mask (per-pixel mode over time), second round."""
+        thr = 1 - stitch_threshold
+        d = ops.to_device_u16(np.ascontiguousarray(masks).astype(np.uint16), _device())
+        Utility._stitch_pass(d, lambda i: d[i - 1], thr, new_ids=True)
+        master = ops.label_mode(d)
+        Utility._stitch_pass(d, lambda i: master, thr, new_ids=False)
+        return ops.to_numpy_u16(d).astype(np.asarray(masks).dtype)
+
     # ------------------------------------------------------------------ distance map (utility.py:829-876)
     @staticmethod
     def ref_mask(imgFold_path, maskLabel, ref_mask_ow=False):

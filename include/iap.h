@@ -157,6 +157,24 @@ int iap_masked_gather_u16(const uint16_t* mask, const int32_t* sq, const uint16_
                           const int64_t* frame_base, double pix_size, int64_t total, int32_t* out_d,
                           uint16_t* out_v, void* stream);
 
+/* ------------------------------------------------------------------ mask stitching ------- */
+
+/* SURVEY 8f rank 3, the array work of Utility.modif_stitch3D (utility.py:700-738).
+ * iap_label_overlap_u16: cellpose.metrics._label_overlap for n plane pairs of px pixels:
+ *   overlap[p][i][j] = #{a == i and b == j}, u32 [n][na_max+1][nb_max+1], zeroed by the call (labels
+ *   above the bounds are ignored).  IoU = overlap / (row sum + column sum - overlap) is left to the host.
+ * iap_relabel_u16: out = lut[frame][in] (masks[i] = istitch[masks[i]], utility.py:724,735); lut_stride
+ *   elements between the tables of consecutive frames (0: one table for all).
+ * iap_label_mode_u16: master mask of utility.py:707-711: per pixel the most frequent non-zero label over T
+ *   frames (ties: the smaller label; 0 when never labelled).  Pixels with more than 8 distinct labels get
+ *   65535 and are counted in *n_overflow (device u32) for the caller to redo. */
+int iap_label_overlap_u16(const uint16_t* a, const uint16_t* b, int64_t n, int64_t px, int na_max, int nb_max,
+                          uint32_t* overlap, void* stream);
+int iap_relabel_u16(const uint16_t* in, uint16_t* out, int64_t n, int64_t px, const uint16_t* lut,
+                    int lut_stride, void* stream);
+int iap_label_mode_u16(const uint16_t* masks, int T, int64_t px, uint16_t* out, uint32_t* n_overflow,
+                       void* stream);
+
 /* ------------------------------------------------------------------ plane files (host) -- */
 
 /* The step on either side of the hot path: the reference keeps every

@@ -529,3 +529,84 @@ def pixel_table(cell_mask: np.ndarray, img: np.ndarray, ref_mask: np.ndarray, pi
     dmap = np.round(dist[sel] * pix_size).astype(int)
     vals = np.stack([np.asarray(img[c])[sel] for c in range(img.shape[0])], axis=1)
     return dmap, vals
+
+
+# ---------------------------------------------------------------- mask stitching
+def label_overlap(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """cellpose.metrics._label_overlap: overlap[i, j] = #{a == i and b == j} (cellpose is absent from the
+    image; this is its published definition, used by utility.py:718)."""
+    a = np.asarray(a).ravel().astype(np.int64)
+    b = np.asarray(b).ravel().astype(np.int64)
+    na, nb = int(a.max()) + 1, int(b.max()) + 1
+    return np.bincount(a * nb + b, minlength=na * nb).reshape(na, nb)
+
+
+def iou_matrix(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """cellpose.metrics._intersection_over_union(masks_true=a, masks_pred=b)."""
+    ov = label_overlap(a, b).astype(np.float64)
+    n_pred = ov.sum(axis=0, keepdims=True)
+    n_true = ov.sum(axis=1, keepdims=True)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        iou = ov / (n_pred + n_true - ov)
+    iou[np.isnan(iou)] = 0.0
+    return iou
+
+
+def label_mode(masks: np.ndarray) -> np.ndarray:
+    """utility.py:707-711: scipy.stats.mode over axis 0 of the stack with zeros as nan (omitted), as int:
+    the most frequent non-zero label per pixel, ties to the smaller label, 0 where never labelled."""
+    m = np.asarray(masks)
+    t = m.shape[0]
+    flat = m.reshape(t, -1)
+    out = np.zeros(flat.shape[1], dtype=np.int64)
+    for k in range(flat.shape[1]):
+        v = flat[:, k]
+        v = v[v != 0]
+        if v.size:
+            vals, cnt = np.unique(v, return_counts=True)
+            out[k] = vals[np.argmax(cnt)]
+    return out.reshape(m.shape[1:])
+
+
+def _stitch_pass(masks: np.ndarray, ref_of, stitch_threshold: float, new_ids: bool) -> np.ndarray:
+    """The loop body shared by Cellpose's stitch3D (new_ids=True: unmatched cells get fresh ids; frame i is
+    matched to frame i-1) and the second round of utility.py:717-737 (new_ids=False: unmatched cells are
+    dropped; every frame is matched to the master mask)."""
+    masks = masks.copy()
+    mmax = int(masks[0].max())
+    empty = 0
+    rng = range(1, len(masks)) if new_ids else range(len(masks))
+    for i in rng:
+        iou = iou_matrix(masks[i], ref_of(masks, i))[1:, 1:]
+        if not iou.size and empty == 0:
+            mmax = int(masks[i].max())
+        elif not iou.size and not empty == 0:
+            icount = int(masks[i].max())
+            istitch = np.arange(mmax + 1, mmax + icount + 1, 1, int)
+            mmax += icount
+            istitch = np.append(np.array(0), istitch)
+            masks[i] = istitch[masks[i]]
+        else:
+            iou[iou < stitch_threshold] = 0.0
+            iou[iou < iou.max(axis=0)] = 0.0
+            istitch = iou.argmax(axis=1) + 1
+            ino = np.nonzero(iou.max(axis=1) == 0.0)[0]
+            if new_ids:
+                istitch[ino] = np.arange(mmax + 1, mmax + len(ino) + 1, 1, int)
+                mmax += len(ino)
+            else:
+                istitch[ino] = 0
+            istitch = np.append(np.array(0), istitch)
+            masks[i] = istitch[masks[i]]
+            empty = 1
+    return masks
+
+
+def modif_stitch3D(masks: np.ndarray, stitch_threshold: float) -> np.ndarray:
+    """utility.py:700-738 on a (T, Y, X) integer label stack.  The first round is Cellpose's stitch3D
+    (un-vendored third party, version unpinned in environment.yml: restated from its published source,
+    parity unpinned); the master mask and the second round are the reference's own lines 705-737."""
+    thr = 1 - stitch_threshold
+    m = _stitch_pass(np.asarray(masks).astype(np.int64), lambda mm, i: mm[i - 1], thr, new_ids=True)
+    master = label_mode(m)
+    return _stitch_pass(m, lambda mm, i: master, thr, new_ids=False)
