@@ -432,3 +432,27 @@ def label_mode(masks: torch.Tensor) -> torch.Tensor:
             fix[k] = vals[np.argmax(cnt)] if len(vals) else 0
         flat[idx] = torch.from_numpy(fix.view(np.int16)).to(masks.device)
     return out
+
+
+# ---------------------------------------------------------------- compartment masks
+def _label_morph(name: str, masks: torch.Tensor, radius: int, iterations: int) -> torch.Tensor:
+    _need_cuda(masks)
+    _u16(masks)
+    n, y, x = _planes(masks)
+    out = torch.empty_like(masks)
+    nbytes = masks.numel() * 2 if iterations > 1 else 0
+    ws = _workspace(nbytes, masks.device) if nbytes else None
+    fn = getattr(_lib.load(), name)
+    _lib.check(fn(masks.data_ptr(), out.data_ptr(), n, y, x, int(radius), int(iterations),
+                  ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, _stream()), name)
+    return out
+
+
+def label_erode(masks: torch.Tensor, radius: int, iterations: int = 1) -> torch.Tensor:
+    """utility.py:776-801 on u16 label planes (..., Y, X): label-preserving erosion with skimage's disk(radius)."""
+    return _label_morph("iap_label_erode_u16", masks, radius, iterations)
+
+
+def label_dilate(masks: torch.Tensor, radius: int, iterations: int = 1) -> torch.Tensor:
+    """utility.py:804-826 on u16 label planes (..., Y, X): grey dilation (largest label) with disk(radius)."""
+    return _label_morph("iap_label_dilate_u16", masks, radius, iterations)

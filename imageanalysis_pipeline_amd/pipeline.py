@@ -333,6 +333,21 @@ class Utility:
         Utility._stitch_pass(d, lambda i: master, thr, new_ids=False)
         return ops.to_numpy_u16(d).astype(np.asarray(masks).dtype)
 
+    # ------------------------------------------------------------------ compartments (utility.py:776-826)
+    @staticmethod
+    def erode_mask(mask_stack, exp_para, rad_ero, **kwargs):
+        """utility.py:776-801: per-object cv2.erode with disk(rad_ero), summed; kwargs: iterations."""
+        d = ops.to_device_u16(np.ascontiguousarray(mask_stack).astype(np.uint16), _device())
+        out = ops.label_erode(d, int(rad_ero), int(kwargs.get("iterations", 1)))
+        return ops.to_numpy_u16(out).astype(np.float64)      # the reference accumulates into np.zeros(shape)
+
+    @staticmethod
+    def dilate_mask(mask_stack, exp_para, rad_dil, **kwargs):
+        """utility.py:804-826: cv2.dilate of the label planes with disk(rad_dil); kwargs: iterations."""
+        d = ops.to_device_u16(np.ascontiguousarray(mask_stack).astype(np.uint16), _device())
+        out = ops.label_dilate(d, int(rad_dil), int(kwargs.get("iterations", 1)))
+        return ops.to_numpy_u16(out).astype(np.float64)
+
     # ------------------------------------------------------------------ distance map (utility.py:829-876)
     @staticmethod
     def ref_mask(imgFold_path, maskLabel, ref_mask_ow=False):

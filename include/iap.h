@@ -175,6 +175,18 @@ int iap_relabel_u16(const uint16_t* in, uint16_t* out, int64_t n, int64_t px, co
 int iap_label_mode_u16(const uint16_t* masks, int T, int64_t px, uint16_t* out, uint32_t* n_overflow,
                        void* stream);
 
+/* ------------------------------------------------------------------ compartment masks ---- */
+
+/* SURVEY 8f rank 4.  Utility.erode_mask (utility.py:776-801): the sum over objects of
+ * cv2.erode(mask == obj ? obj : 0, disk(r), iterations) = a pixel keeps its label iff the whole disk round
+ * it (inside the image) carries that label; Utility.dilate_mask (utility.py:804-826): cv2.dilate of the
+ * label image = largest label inside the disk.  disk(r): dx^2 + dy^2 <= r^2, r <= 31.  n planes of Y x X;
+ * in != out; iterations > 1 need ws of n*Y*X*2 bytes (distinct from in and out). */
+int iap_label_erode_u16(const uint16_t* in, uint16_t* out, int64_t n, int Y, int X, int radius, int iterations,
+                        void* ws, size_t ws_bytes, void* stream);
+int iap_label_dilate_u16(const uint16_t* in, uint16_t* out, int64_t n, int Y, int X, int radius, int iterations,
+                         void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------ plane files (host) -- */
 
 /* The step on either side of the hot path: the reference keeps every

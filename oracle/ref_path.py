@@ -610,3 +610,41 @@ def modif_stitch3D(masks: np.ndarray, stitch_threshold: float) -> np.ndarray:
     m = _stitch_pass(np.asarray(masks).astype(np.int64), lambda mm, i: mm[i - 1], thr, new_ids=True)
     master = label_mode(m)
     return _stitch_pass(m, lambda mm, i: master, thr, new_ids=False)
+
+
+# ---------------------------------------------------------------- compartment masks
+def disk_offsets(r: int):
+    """skimage.morphology.disk(r) as (dy, dx) offsets: dx^2 + dy^2 <= r^2."""
+    return [(dy, dx) for dy in range(-r, r + 1) for dx in range(-r, r + 1) if dy * dy + dx * dx <= r * r]
+
+
+def label_erode(mask: np.ndarray, r: int, iterations: int = 1) -> np.ndarray:
+    """utility.py:776-801 for one 2-D label plane: sum over objects of cv2.erode(mask == obj ? obj : 0,
+    disk(r)) (cv2 absent: erosion = minimum over the footprint, border value +inf, i.e. pixels outside the
+    image never erode; pinned against scipy.ndimage.grey_erosion per object in tests/golden)."""
+    m = np.asarray(mask).astype(np.int64)
+    y, x = m.shape
+    for _ in range(iterations):
+        keep = m != 0
+        for dy, dx in disk_offsets(r):
+            sh = np.full_like(m, -1)                       # -1 = outside the image: matches everything
+            ys, yd = slice(max(dy, 0), y + min(dy, 0)), slice(max(-dy, 0), y + min(-dy, 0))
+            xs, xd = slice(max(dx, 0), x + min(dx, 0)), slice(max(-dx, 0), x + min(-dx, 0))
+            sh[yd, xd] = m[ys, xs]
+            keep &= (sh == m) | (sh == -1)
+        m = np.where(keep, m, 0)
+    return m
+
+
+def label_dilate(mask: np.ndarray, r: int, iterations: int = 1) -> np.ndarray:
+    """utility.py:804-826 for one 2-D label plane: cv2.dilate(mask, disk(r)) = maximum over the footprint."""
+    m = np.asarray(mask).astype(np.int64)
+    y, x = m.shape
+    for _ in range(iterations):
+        out = m.copy()
+        for dy, dx in disk_offsets(r):
+            ys, yd = slice(max(dy, 0), y + min(dy, 0)), slice(max(-dy, 0), y + min(-dy, 0))
+            xs, xd = slice(max(dx, 0), x + min(dx, 0)), slice(max(-dx, 0), x + min(-dx, 0))
+            out[yd, xd] = np.maximum(out[yd, xd], m[ys, xs])
+        m = out
+    return m

@@ -90,6 +90,23 @@ def golden_edt():
     np.savez_compressed(os.path.join(HERE, "edt_scipy.npz"), masks=masks, dist=dist)
 
 
+def golden_morph():
+    """scipy grey erosion/dilation with skimage's disk footprint, per object as utility.py:776-826 does."""
+    from skimage.morphology import disk
+    lab = synth.make_labels(80, 100, 7, seed=6).astype(np.int64)
+    lab[:6, :9] = 8                                             # an object touching the image corner
+    out = {}
+    for r in (1, 3, 6):
+        fp = disk(r)
+        ero = np.zeros_like(lab)
+        for obj in np.unique(lab)[1:]:
+            t = np.where(lab == obj, obj, 0)
+            ero += ndi.grey_erosion(t, footprint=fp, mode="constant", cval=1 << 40)
+        out[f"erode_{r}"] = ero
+        out[f"dilate_{r}"] = ndi.grey_dilation(lab, footprint=fp, mode="constant", cval=0)
+    np.savez_compressed(os.path.join(HERE, "morph_scipy.npz"), labels=lab.astype(np.uint16), **out)
+
+
 if __name__ == "__main__":
     golden_regionprops()
     golden_shift()
@@ -97,3 +114,4 @@ if __name__ == "__main__":
     golden_xcorr()
     print("golden fixtures written to", HERE)
     golden_edt()
+    golden_morph()

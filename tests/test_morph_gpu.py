@@ -1,0 +1,63 @@
+"""Label-preserving erosion / dilation with a disk (Utility.erode_mask / dilate_mask,
+utility.py:776-826) through the C-ABI against the oracle (pinned to scipy's grey morphology by
+tests/golden/morph_scipy.npz; cv2 itself is absent: unpinned vs OpenCV).  Integer work: bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from imageanalysis_pipeline_amd import ops, synth
+from imageanalysis_pipeline_amd.pipeline import Utility
+from oracle import ref_path as O
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_golden_and_oracle(dev):
+    g = np.load(os.path.join(GOLDEN, "morph_scipy.npz"))
+    d = ops.to_device_u16(g["labels"], dev)
+    for r in (1, 3, 6):
+        assert np.array_equal(ops.to_numpy_u16(ops.label_erode(d, r)), g[f"erode_{r}"])
+        assert np.array_equal(ops.to_numpy_u16(ops.label_dilate(d, r)), g[f"dilate_{r}"])
+    lab = synth.make_labels(150, 211, 14, seed=4).astype(np.uint16)      # odd sizes, touching objects possible
+    lab[100:150, 180:211] = 77                                           # object on the border
+    dl = ops.to_device_u16(np.stack([lab, lab[::-1].copy()]), dev)
+    for r, it in ((0, 1), (10, 1), (31, 1), (4, 3), (5, 2)):
+        e = ops.to_numpy_u16(ops.label_erode(dl, r, it))
+        dd = ops.to_numpy_u16(ops.label_dilate(dl, r, it))
+        for k, src in enumerate((lab, lab[::-1])):
+            assert np.array_equal(e[k], O.label_erode(src, r, it)), (r, it)
+            assert np.array_equal(dd[k], O.label_dilate(src, r, it)), (r, it)
+
+
+def test_full_size_properties(dev):
+    """2048 x 2048: eroded labels are a subset of the input labels, dilation contains them, and a disc of
+    radius R eroded by r is the disc of radius R - r (up to the lattice)."""
+    y = x = 2048
+    yy, xx = np.mgrid[0:y, 0:x]
+    lab = np.zeros((y, x), np.uint16)
+    lab[(yy - 1000) ** 2 + (xx - 900) ** 2 <= 200 ** 2] = 5
+    d = ops.to_device_u16(lab, dev)
+    e = ops.to_numpy_u16(ops.label_erode(d, 20))
+    dl = ops.to_numpy_u16(ops.label_dilate(d, 20))
+    assert ((e == 0) | (e == lab)).all() and ((dl == lab) | (lab == 0)).all()
+    inner = (yy - 1000) ** 2 + (xx - 900) ** 2 <= 179 ** 2
+    outer = (yy - 1000) ** 2 + (xx - 900) ** 2 <= 181 ** 2
+    assert (e[inner] == 5).all() and (e[~outer] == 0).all()
+
+
+def test_shim_erode_dilate_and_errors(dev):
+    lab = synth.make_labels(64, 96, 6, seed=9).astype(np.uint16)
+    stack = np.stack([lab, np.roll(lab, 3, 1)])
+    para = {"t": 2, "z": 1}
+    e = Utility.erode_mask(stack, para, 3, iterations=2)
+    d = Utility.dilate_mask(stack, para, 2)
+    assert e.shape == stack.shape and e.dtype == np.float64            # np.zeros(...) accumulation of the reference
+    for k in range(2):
+        assert np.array_equal(e[k], O.label_erode(stack[k], 3, 2))
+        assert np.array_equal(d[k], O.label_dilate(stack[k], 2))
+    single = Utility.erode_mask(lab, {"t": 1, "z": 1}, 3)
+    assert single.shape == lab.shape and np.array_equal(single, O.label_erode(lab, 3))
+    with pytest.raises(ValueError):
+        ops.label_erode(ops.to_device_u16(lab, dev), 40)

@@ -108,3 +108,14 @@ def test_pixel_table_order_and_rounding():
     # row-major order: (0,5), (1,2), (4,0); distances 5, sqrt(5), 4 -> x0.5 -> 2.5, 1.118, 2.0 -> round-half-even
     assert dmap.tolist() == [2, 1, 2]
     assert vals.tolist() == [[5, 53], [10, 58], [32, 80]]
+
+
+def test_label_morphology_vs_scipy():
+    """oracle label_erode / label_dilate against scipy grey morphology with skimage's disk (golden)."""
+    g = np.load(os.path.join(G, "morph_scipy.npz"))
+    lab = g["labels"]
+    for r in (1, 3, 6):
+        assert np.array_equal(O.label_erode(lab, r), g[f"erode_{r}"])
+        assert np.array_equal(O.label_dilate(lab, r), g[f"dilate_{r}"])
+    # iterations = repeated application (cv2 iterations=)
+    assert np.array_equal(O.label_erode(lab, 2, iterations=2), O.label_erode(O.label_erode(lab, 2), 2))
