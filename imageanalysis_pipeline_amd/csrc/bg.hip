@@ -540,13 +540,13 @@ __global__ __launch_bounds__(256) void sub_half_kernel(const uint16_t* __restric
   const long long nv = plane_px >> 3;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv;
        i += (long long)gridDim.x * blockDim.x) {
-    u16x8 v = load8(pi + i * 8);
+    u16x8 v = load8_nt(pi + i * 8);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       int d = 2 * (int)v.v[k] - s2;
       v.v[k] = (uint16_t)(d > 0 ? (d >> 1) : 0);
     }
-    store8(po + i * 8, v);
+    store8_nt(po + i * 8, v);
   }
   if (blockIdx.x == 0) {  // tail of planes whose pixel count is not a multiple of 8
     long long i = nv * 8 + threadIdx.x;

@@ -66,6 +66,19 @@ struct alignas(16) u16x8 {
 
 __device__ __forceinline__ u16x8 load8(const uint16_t* p) { return *reinterpret_cast<const u16x8*>(p); }
 __device__ __forceinline__ void store8(uint16_t* p, const u16x8& v) { *reinterpret_cast<u16x8*>(p) = v; }
+// streaming variants: data that is not touched again soon (keeps it from displacing reusable lines)
+typedef unsigned iap_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u16x8 load8_nt(const uint16_t* p) {
+  iap_u32x4 w = __builtin_nontemporal_load(reinterpret_cast<const iap_u32x4*>(p));
+  u16x8 v;
+  __builtin_memcpy(&v, &w, 16);
+  return v;
+}
+__device__ __forceinline__ void store8_nt(uint16_t* p, const u16x8& v) {
+  iap_u32x4 w;
+  __builtin_memcpy(&w, &v, 16);
+  __builtin_nontemporal_store(w, reinterpret_cast<iap_u32x4*>(p));
+}
 
 // XCD-aware block remap (guide T1): blocks b and b+8 share an XCD/L2; give each XCD a
 // contiguous range of logical tiles.  Bijective for any n.

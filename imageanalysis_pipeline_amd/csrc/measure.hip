@@ -110,12 +110,12 @@ __global__ __launch_bounds__(MEAS_THREADS) void measure_kernel(
     uint16_t lv[VEC];
     uint16_t iv[NC][VEC];
     if (VEC == 8) {
-      u16x8 l8 = load8(lab_f + p);
+      u16x8 l8 = load8_nt(lab_f + p);
 #pragma unroll
       for (int i = 0; i < 8; ++i) lv[i] = l8.v[i];
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        u16x8 i8 = load8(img_f + (size_t)c * zyx + p);
+        u16x8 i8 = load8_nt(img_f + (size_t)c * zyx + p);   // image planes stream through once
 #pragma unroll
         for (int i = 0; i < 8; ++i) iv[c][i] = i8.v[i];
       }

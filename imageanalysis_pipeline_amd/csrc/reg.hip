@@ -26,6 +26,13 @@ namespace iap {
 
 typedef float2 cf;
 
+// streaming 8-byte load of one complex value (spectra that are read exactly once by a kernel)
+typedef float cf_v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cf load_cf_nt(const cf* p) {
+  cf_v2 w = __builtin_nontemporal_load(reinterpret_cast<const cf_v2*>(p));
+  return make_float2(w.x, w.y);
+}
+
 __device__ __forceinline__ cf cmul(cf a, cf b) {
   return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
 }
@@ -314,7 +321,7 @@ __global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_c2r_argmax
   const cf* Qa = Q + (size_t)blockIdx.y * Q_stride + (size_t)ra * Wp;
   const cf* Qb = Qa + Wp;
   for (int k = j; k <= N / 2; k += Gm::NT) {
-    cf a = Qa[k], b = Qb[k];
+    cf a = load_cf_nt(Qa + k), b = load_cf_nt(Qb + k);
     if (k == 0 || k == N / 2) {  // c2r convention: the imaginary parts of the self-conjugate bins are ignored
       a.y = 0.f;
       b.y = 0.f;
@@ -993,11 +1000,7 @@ __global__ __launch_bounds__(256, AP_MIN_WAVES) void apply_shift_kernel(const ui
           const int yy = oy + y0 + k;
           const bool inside = xin && yy >= ay.lo && yy <= ay.hi;
           const float v = inside ? fminf(fmaxf(res[k], 0.f), 65535.f) : 0.f;
-#ifdef IAP_AP_NOSTORE
-          if (yy < Y && v == 12345.5f) po[(size_t)yy * X + xx] = (uint16_t)(unsigned)v;
-#else
-          if (yy < Y) po[(size_t)yy * X + xx] = (uint16_t)(unsigned)v;   // truncation toward zero
-#endif
+          if (yy < Y) __builtin_nontemporal_store((uint16_t)(unsigned)v, po + (size_t)yy * X + xx);   // truncation toward zero; written once, not re-read here
         }
       }
     }
