@@ -716,7 +716,7 @@ static int launch_gauss_reflect(const T* in, float* tmp, float* out, int64_t n, 
   return IAP_OK;
 }
 
-constexpr int64_t BG_BATCH_BYTES = 512ll << 20;  // planes per batch (measured on 256 planes: 192 MB 9.0, 256 MB 8.5, 512 MB 8.1, 1 GB 8.1 us/plane)
+constexpr int64_t BG_BATCH_BYTES = 1024ll << 20;  // planes per batch: long launches hide the march tail (C2 step: 512 MB 49.0, 1 GB 48.0, 2 GB 47.8 ms)
 
 }  // namespace iap
 
