@@ -231,52 +231,67 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_kerne
   const int tid = threadIdx.x;
   const int c = tid / Gm::CNT, j = tid % Gm::CNT;
   cf* s = lds_c + c * Gm::CS;
+  const unsigned frame = blockIdx.y;
   const int v0 = xcd_remap(blockIdx.x, gridDim.x) * Gm::TC;
-  cf* Ff = F + (size_t)blockIdx.y * F_stride;
+  cf* Ff = F + (size_t)frame * F_stride;
+  // Tile rows are TC complex values (32 bytes for N = 2048): every lane moves TWO neighbouring columns of
+  // one row as one 16-byte access (half the memory instructions of an 8-byte-per-lane mapping).
+  static_assert(Gm::TC % 2 == 0 && Gm::CE % 2 == 0, "column pairs");
+  constexpr int HP = Gm::TC / 2;                 // column pairs per row
 #pragma unroll 4
-  for (int m = 0; m < Gm::CE; ++m) {
-    int idx = tid + m * NTH;
-    int cc = idx % Gm::TC, u = idx / Gm::TC;
-    lds_c[cc * Gm::CS + padi(u)] = Ff[(size_t)u * Wp + v0 + cc];
+  for (int m = 0; m < Gm::CE / 2; ++m) {
+    const int idx = tid + m * NTH;               // pair index: (row u, pair pc)
+    const int pc = idx % HP, u = idx / HP;
+    const float4 w = *reinterpret_cast<const float4*>(Ff + (size_t)u * Wp + v0 + 2 * pc);
+    lds_c[(2 * pc) * Gm::CS + padi(u)] = make_float2(w.x, w.y);
+    lds_c[(2 * pc + 1) * Gm::CS + padi(u)] = make_float2(w.z, w.w);
   }
   __syncthreads();
   fft_lds<N, -1, Gm::CE>(s, j, tw);
   if (mode == 1) {
-    cf* Rf = R ? R + (size_t)blockIdx.y * R_stride : nullptr;
+    cf* Rf = R ? R + (size_t)frame * R_stride : nullptr;
 #pragma unroll 4
-    for (int m = 0; m < Gm::CE; ++m) {
-      int idx = tid + m * NTH;
-      int cc = idx % Gm::TC, u = idx / Gm::TC;
-      cf g = lds_c[cc * Gm::CS + padi(u)];
-      cf f = Gref[(size_t)v0 * N + idx];
-      cf p = make_float2((f.x * g.x + f.y * g.y) * scale, (f.y * g.x - f.x * g.y) * scale);
-      if (normalize) {
-        float m2 = p.x * p.x + p.y * p.y;
-        float inv = m2 > 0.f ? rsqrtf(m2) : 0.f;
-        p.x *= inv;
-        p.y *= inv;
+    for (int m = 0; m < Gm::CE / 2; ++m) {
+      const int idx = tid + m * NTH;
+      const int pc = idx % HP, u = idx / HP;
+      const float4 f2 = *reinterpret_cast<const float4*>(Gref + (size_t)v0 * N + 2 * idx);   // tile-major: [u][cc]
+      cf pp[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const cf g = lds_c[(2 * pc + h) * Gm::CS + padi(u)];
+        const cf f = h ? make_float2(f2.z, f2.w) : make_float2(f2.x, f2.y);
+        cf p = make_float2((f.x * g.x + f.y * g.y) * scale, (f.y * g.x - f.x * g.y) * scale);
+        if (normalize) {
+          float m2 = p.x * p.x + p.y * p.y;
+          float inv = m2 > 0.f ? rsqrtf(m2) : 0.f;
+          p.x *= inv;
+          p.y *= inv;
+        }
+        if (u == 0 && v0 + 2 * pc + h == 0) p = make_float2(0.f, 0.f);
+        lds_c[(2 * pc + h) * Gm::CS + padi(u)] = p;
+        pp[h] = p;
       }
-      if (u == 0 && v0 + cc == 0) p = make_float2(0.f, 0.f);
-      if (Rf) Rf[(size_t)u * Wp + v0 + cc] = p;
-      lds_c[cc * Gm::CS + padi(u)] = p;
+      if (Rf) *reinterpret_cast<float4*>(Rf + (size_t)u * Wp + v0 + 2 * pc) = make_float4(pp[0].x, pp[0].y, pp[1].x, pp[1].y);
     }
     __syncthreads();
     fft_lds<N, +1, Gm::CE>(s, j, tw);
   }
   if (mode == 0) {
 #pragma unroll 4
-    for (int m = 0; m < Gm::CE; ++m) {
-      int idx = tid + m * NTH;
-      int cc = idx % Gm::TC, u = idx / Gm::TC;
-      R[(size_t)v0 * N + idx] = lds_c[cc * Gm::CS + padi(u)];
+    for (int m = 0; m < Gm::CE / 2; ++m) {
+      const int idx = tid + m * NTH;
+      const int pc = idx % HP, u = idx / HP;
+      const cf a = lds_c[(2 * pc) * Gm::CS + padi(u)], b2 = lds_c[(2 * pc + 1) * Gm::CS + padi(u)];
+      *reinterpret_cast<float4*>(R + (size_t)v0 * N + 2 * idx) = make_float4(a.x, a.y, b2.x, b2.y);
     }
     return;
   }
 #pragma unroll 4
-  for (int m = 0; m < Gm::CE; ++m) {
-    int idx = tid + m * NTH;
-    int cc = idx % Gm::TC, u = idx / Gm::TC;
-    Ff[(size_t)u * Wp + v0 + cc] = lds_c[cc * Gm::CS + padi(u)];
+  for (int m = 0; m < Gm::CE / 2; ++m) {
+    const int idx = tid + m * NTH;
+    const int pc = idx % HP, u = idx / HP;
+    const cf a = lds_c[(2 * pc) * Gm::CS + padi(u)], b2 = lds_c[(2 * pc + 1) * Gm::CS + padi(u)];
+    *reinterpret_cast<float4*>(Ff + (size_t)u * Wp + v0 + 2 * pc) = make_float4(a.x, a.y, b2.x, b2.y);
   }
 }
 
