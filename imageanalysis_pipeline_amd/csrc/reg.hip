@@ -905,6 +905,12 @@ __global__ __launch_bounds__(256, AP_MIN_WAVES) void apply_shift_kernel(const ui
     }
   };
   auto stage = [&](int first) {  // the source tile as raw u16 (its readers convert)
+    if (wide && first >= 0 && first + AP_TW <= X) {  // uniform: every staged vector lies inside the row
+#pragma unroll
+      for (int jv = 0; jv < NV; ++jv)
+        if (tid + jv * 256 < NVEC) tile[lds_off[jv]] = q[jv];
+      return;
+    }
 #pragma unroll
     for (int jv = 0; jv < NV; ++jv) {
       if (tid + jv * 256 < NVEC) {
@@ -1009,7 +1015,15 @@ __global__ __launch_bounds__(256, AP_MIN_WAVES) void apply_shift_kernel(const ui
       }
       const int xx = ox + c;
       const bool xin = xx >= ax.lo && xx <= ax.hi;
-      if (xx < X) {
+      // uniform: every output of the tile has its source inside the image and lies inside the plane
+      const bool interior = ox >= ax.lo && ox + AP_TX - 1 <= ax.hi && oy >= ay.lo && oy + TY - 1 <= ay.hi &&
+                            ox + AP_TX <= X && oy + TY <= Y;
+      if (interior) {
+        uint16_t* o0 = po + (size_t)(oy + y0) * X + xx;
+#pragma unroll
+        for (int k = 0; k < YG; ++k)   // clamp, then truncation toward zero; written once, not re-read here
+          __builtin_nontemporal_store((uint16_t)(unsigned)__builtin_amdgcn_fmed3f(res[k], 0.f, 65535.f), o0 + (size_t)k * X);
+      } else if (xx < X) {
 #pragma unroll
         for (int k = 0; k < YG; ++k) {
           const int yy = oy + y0 + k;
