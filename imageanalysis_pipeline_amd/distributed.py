@@ -40,6 +40,8 @@ def gather_rows(rows: torch.Tensor, group=None) -> torch.Tensor:
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return rows
     world = dist.get_world_size(group)
+    if dist.get_backend(group) == "gloo":   # gloo gathers host tensors (tests, rehearsals); RCCL takes device ones
+        rows = rows.cpu()
     n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n, group=group)
@@ -73,6 +75,8 @@ def process_plate(load_fov, n_fov: int, threshold: float, reg_ref: str = "mean",
     width = torch.tensor([rows.shape[1] if rows is not None else 0], dtype=torch.int64,
                          device=parts[0].device if parts else ("cuda" if torch.cuda.is_available() else "cpu"))
     if dist.is_initialized() and world > 1:
+        if dist.get_backend(group) == "gloo":
+            width = width.cpu()
         dist.all_reduce(width, op=dist.ReduceOp.MAX, group=group)
     if rows is None:
         rows = torch.zeros((0, int(width.item())), dtype=torch.float64, device=width.device)
