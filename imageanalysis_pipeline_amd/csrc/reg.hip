@@ -16,8 +16,9 @@
 //   K6 upsample_finish  sum partials, arg-max, parabolic vertex -> (dy, dx) as f64
 // Apply: apply_shift_kernel -- separable cubic B-spline shift = scipy.ndimage.shift(order=3):
 // mirror-boundary prefilter as two one-multiply recursions started from 12 explicit taps
-// (truncation 0.268^12), then the 4-tap evaluation; LDS tiles walked along x; zero outside,
-// clip, truncate to u16.  An axis with an integer shift bypasses the filter: exact copies.
+// (truncation 0.268^12), then the 4-tap evaluation, as packed f32 pairs; a workgroup marches down a
+// 64-column strip and keeps the x-filtered rows two steps share in LDS; zero outside, clip,
+// truncate to u16.  An axis with an integer shift bypasses the filter: exact copies.
 #include <math.h>
 #include <stdlib.h>
 #include "common.h"
@@ -745,18 +746,23 @@ __global__ __launch_bounds__(256) void accum_planes_kernel(const uint16_t* __res
 // out(y,x) = cubic B-spline interpolation of `in` at (y - dy, x - dx): scipy.ndimage.shift(order=3,
 // mode='constant', cval=0), i.e. spline coefficients c = (direct B-spline filter)^-1 s with mirror
 // boundary, then a 4-tap evaluation.  The inverse filter is the two-sided exponential
-// c[k] = c0 * sum_m z1^|m| s[k-m]  (z1 = sqrt(3)-2).  Per axis a thread evaluates a run of
+// c[k] = c0 * sum_m z1^|m| s[k-m]  (z1 = sqrt(3)-2).  Per axis a thread evaluates runs of 8
 // neighbouring outputs: the causal and anti-causal sums are started with R+1 explicit taps
 // (truncation z1^(R+1) ~ 1.4e-7) and continued by the exact one-multiply recursions
-// C+[k+1] = s[k+1] + z1 C+[k],  C-[k-1] = s[k-1] + z1 C-[k]  -> ~12 FMA per sample instead of a
+// C+[k+1] = s[k+1] + z1 C+[k],  C-[k-1] = s[k-1] + z1 C-[k]  -> ~11 FMA per sample instead of a
 // 24-tap FIR.  An axis whose shift is an integer bypasses the filter, so integer shifts are exact
-// copies.  Tiles are staged through LDS: aligned 16-byte loads for interior tiles, mirrored
-// scalar loads at the image border.
+// copies.  Source rows are staged through LDS: unaligned 16-byte loads inside the image, mirrored
+// scalar loads at its border.
+//
+// A workgroup owns a strip of 64 output columns and walks down it 64 rows a step.  The x-filtered
+// rows the next step needs again (2R+3 = 25) stay in LDS, so every source row is staged and
+// x-filtered once per strip.  Both passes work on packed f32 pairs (v_pk_fma_f32 issues at the
+// rate of v_fma_f32 here): a thread runs the columns c and c+32 together, which halves the FMA
+// issue count -- the tile kernel this replaces was bound by VALU issue, not by HBM.
 constexpr int AP_R = 11;
-constexpr int AP_TX = 64;
-constexpr int AP_TW = 96;      // staged columns, starting at the first sample the tile needs: 12 u16x8 vectors
+constexpr int AP_TX = 64;      // output columns per strip
+constexpr int AP_TW = 96;      // staged columns, starting at the first sample the strip needs: 12 u16x8 vectors
 constexpr int AP_PITCH = 104;  // u16 per staged row = 52 dwords = 4 * odd: 16-byte reads by lanes on consecutive rows hit distinct banks
-constexpr int AP_XG = 16;      // outputs per thread in the x pass
 constexpr float AP_Z1 = -0.26794919243112270647f;
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -795,61 +801,80 @@ __device__ __forceinline__ AxisParams axis_params(double d, int n) {
   return a;
 }
 
-// NOUT outputs from NOUT + 2*AP_R + 3 consecutive samples s[0..]: s[AP_R + 1 + k] is the sample
-// under output k (i0 of output k), coefficients k-1 .. k+2 are needed for output k.
-template <int NOUT>
-__device__ __forceinline__ void spline_run(const float* s, const float (&w)[4], float* out) {
+constexpr int AM_TY = 64;                    // output rows per step
+constexpr int AM_HALO = 2 * AP_R + 3;        // x-filtered rows carried from step to step
+constexpr int AM_CP = 90;                    // rows per column pair: 180 dwords = 4 * odd -> conflict-free 16-byte reads
+constexpr int AM_G = 8;                      // outputs per run (x and y)
+static_assert(AM_TY + AM_HALO + 1 <= AM_CP, "a step's rows fit one column of colp");
+
+__device__ __forceinline__ v2f sp_splat(float v) { return (v2f){v, v}; }
+__device__ __forceinline__ v2f sp_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+// NOUT outputs of two runs (the halves of a pair) from NOUT + 2*AP_R + 3 consecutive samples each:
+// `s(i)` returns sample i, the sample under output k is i = AP_R + 1 + k, coefficients k-1 .. k+2
+// feed output k.  Two sweeps, so that few values are live at once: the causal sums upwards (kept),
+// then downwards the anti-causal sum, the coefficient and its four contributions to the outputs;
+// `mid()` runs between them (the caller fetches what only the second sweep reads).
+template <int NOUT, typename F, typename M>
+__device__ __forceinline__ void spline_run2(F s, M mid, const float (&w)[4], v2f* out) {
   constexpr int NC = NOUT + 3;           // coefficients q = -1 .. NOUT+1
-  float cp[NC], cm[NC];
-  // causal start at q = -1: sample index of q is AP_R + 1 + q
+  const v2f z = sp_splat(AP_Z1);
+  const v2f w0 = sp_splat(w[0]), w1 = sp_splat(w[1]), w2 = sp_splat(w[2]), w3 = sp_splat(w[3]);
+  v2f cp[NC];
   {
-    float a = s[0];                       // oldest tap, Horner from the far end
+    v2f a = s(0);
 #pragma unroll
-    for (int m = 1; m <= AP_R; ++m) a = fmaf(a, AP_Z1, s[m]);
-    cp[0] = a;                            // = sum_{m=0..R} z^m s[AP_R - m]
+    for (int m = 1; m <= AP_R; ++m) a = sp_fma(a, z, s(m));
+    cp[0] = a;
   }
 #pragma unroll
-  for (int q = 1; q < NC; ++q) cp[q] = fmaf(cp[q - 1], AP_Z1, s[AP_R + q]);
-  {
-    float a = s[NC - 1 + 2 * AP_R];
+  for (int q = 1; q < NC; ++q) cp[q] = sp_fma(cp[q - 1], z, s(AP_R + q));
+  mid();
+  v2f cm = s(NC - 1 + 2 * AP_R);         // anti-causal sum of coefficient q + 1 while q is worked on
 #pragma unroll
-    for (int m = 1; m <= AP_R; ++m) a = fmaf(a, AP_Z1, s[NC - 1 + 2 * AP_R - m]);
-    cm[NC - 1] = a;                       // = sum_{m=0..R} z^m s[AP_R + NC - 1 + m]
+  for (int m = 1; m <= AP_R; ++m) cm = sp_fma(cm, z, s(NC - 1 + 2 * AP_R - m));
+#pragma unroll
+  for (int q = NC - 1; q >= 0; --q) {
+    v2f c;                               // coefficient / c0 = C+ + C- - s, and C-[q] - s[q] = z1 C-[q+1]
+    if (q == NC - 1) {
+      c = (cp[q] + cm) - s(AP_R + q);
+    } else {
+      c = sp_fma(cm, z, cp[q]);
+      if (q > 0) cm = sp_fma(cm, z, s(AP_R + q));
+    }
+    if (q - 3 >= 0 && q - 3 < NOUT) out[q - 3] = w3 * c;
+    if (q - 2 >= 0 && q - 2 < NOUT) out[q - 2] = sp_fma(w2, c, out[q - 2]);
+    if (q - 1 >= 0 && q - 1 < NOUT) out[q - 1] = sp_fma(w1, c, out[q - 1]);
+    if (q < NOUT) out[q] = sp_fma(w0, c, out[q]);
   }
-#pragma unroll
-  for (int q = NC - 2; q >= 0; --q) cm[q] = fmaf(cm[q + 1], AP_Z1, s[AP_R + q]);
-  // coefficient / c0 = C+ + C- - s, and C-[q] - s[q] = z1 C-[q+1]: one FMA per coefficient
-  cp[NC - 1] = (cp[NC - 1] + cm[NC - 1]) - s[AP_R + NC - 1];
-#pragma unroll
-  for (int q = 0; q < NC - 1; ++q) cp[q] = fmaf(cm[q + 1], AP_Z1, cp[q]);
-#pragma unroll
-  for (int k = 0; k < NOUT; ++k)
-    out[k] = fmaf(w[0], cp[k], fmaf(w[1], cp[k + 1], fmaf(w[2], cp[k + 2], w[3] * cp[k + 3])));
 }
 
-#ifndef AP_MIN_WAVES
-#define AP_MIN_WAVES 4
+// mirror index for the common single reflection, the general form otherwise
+__device__ __forceinline__ int reflect_near(int i, int n) {
+  int a = i < 0 ? -i : i;
+  a = a >= n ? 2 * (n - 1) - a : a;
+  if ((unsigned)a >= (unsigned)n) a = reflect101_idx(i, n);
+  return a;
+}
+
+#ifndef AM_MIN_WAVES
+#define AM_MIN_WAVES 4
 #endif
-template <int TY>
-__global__ __launch_bounds__(256, AP_MIN_WAVES) void apply_shift_kernel(const uint16_t* __restrict__ in,
-                                                          uint16_t* __restrict__ out, long long planes_per_frame,
-                                                          int Y, int X, const double* __restrict__ shifts, int ntx) {
-  constexpr int TH = TY + 2 * AP_R + 3;                  // staged rows
-  constexpr int YG = TY / 4;                             // outputs per thread in the y pass (4 row groups x 64 columns)
-  constexpr int XS = (AP_XG + 2 * AP_R + 3 + 7) & ~7;    // samples an x run reads (whole 16-byte vectors of u16)
-  constexpr int YS = (YG + 2 * AP_R + 3 + 3) & ~3;       // samples a y run reads
-  constexpr int CP0 = (TY - YG + YS + 3) & ~3;
-  constexpr int CP = (CP0 / 4) % 2 ? CP0 : CP0 + 4;      // pitch of the transposed x-filtered tile: 4 * odd
-  constexpr int NVEC = TH * (AP_TW / 8);                 // 16-byte vectors per staged tile
-  constexpr int NV = (NVEC + 255) / 256;                 // ... per thread
-  static_assert((AP_TX / AP_XG - 1) * AP_XG + XS <= AP_TW, "x runs stay inside the staged columns");
-  static_assert(AP_PITCH % 8 == 0, "rows are whole 16-byte vectors");
-  __shared__ u32x4 tile[TH * (AP_PITCH / 8)];            // source tile as u16x8 vectors; column 0 = first sample needed
-  __shared__ __align__(16) float colp[AP_TX * CP];       // after the x pass, transposed: [column][row]
+__global__ __launch_bounds__(256, AM_MIN_WAVES) void apply_shift_kernel(const uint16_t* __restrict__ in,
+                                                                        uint16_t* __restrict__ out,
+                                                                        long long planes_per_frame, int Y, int X,
+                                                                        const double* __restrict__ shifts, int nty) {
+  constexpr int VPR = AP_TW / 8;                 // 16-byte vectors per staged row
+  constexpr int LP = AP_PITCH / 8;               // ... per LDS row
+  constexpr int NV = AM_TY * VPR / 256;          // vectors a thread stages per step
+  static_assert(AM_TY * VPR % 256 == 0, "whole rounds of staging");
+  static_assert((AP_TX / 2 / AM_G - 1) * AM_G + 32 + AM_G + 2 * AP_R + 3 <= AP_TW, "x runs stay inside the staged columns");
+  __shared__ u32x4 tile[AM_TY * LP];             // the step's new source rows, raw u16
+  __shared__ __align__(16) v2f colp[(AP_TX / 2) * AM_CP];   // x-filtered rows: [column pair (c, c+32)][row]
   __shared__ AxisParams pay, pax;
   const int tid = threadIdx.x;
 #ifdef IAP_AP_STAMPS
-  long long t_last = clock64(), t_acc[6] = {0, 0, 0, 0, 0, 0};
+  long long t_last = clock64(), t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   const long long plane = blockIdx.z;
   const long long frame = plane / planes_per_frame;
@@ -859,185 +884,212 @@ __global__ __launch_bounds__(256, AP_MIN_WAVES) void apply_shift_kernel(const ui
     else pax = a;
   }
   __syncthreads();
-  const AxisParams ay = pay, ax = pax;
-  // XCD-aware placement: every XCD (blocks b, b+8, ... share one) gets a contiguous band of
-  // rows, so the halo rows two vertically adjacent workgroups both read are served by one L2
+  // wave-uniform: keep the parameters in scalar registers
+  auto uniform = [](const AxisParams& a) {
+    AxisParams u;
+    u.sh = __builtin_amdgcn_readfirstlane(a.sh);
+    u.lo = __builtin_amdgcn_readfirstlane(a.lo);
+    u.hi = __builtin_amdgcn_readfirstlane(a.hi);
+    u.whole = __builtin_amdgcn_readfirstlane(a.whole);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u.w[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.w[i])));
+    return u;
+  };
+  const AxisParams ay = uniform(pay), ax = uniform(pax);
+  // strips next to each other (consecutive ids) run on one XCD: the 32 columns they both stage come from one L2
   const unsigned lin = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-  const unsigned bxi = lin % gridDim.x, byi = lin / gridDim.x;
-  const int oy = byi * TY;
+  const int ox = (lin % gridDim.x) * AP_TX;
+  const int tiles_y = (Y + AM_TY - 1) / AM_TY;
+  const int ty0 = (lin / gridDim.x) * nty, ty1 = min(ty0 + nty, tiles_y);
   const uint16_t* __restrict__ p = in + (size_t)plane * Y * X;
   uint16_t* __restrict__ po = out + (size_t)plane * Y * X;
-  const int yend = min(oy + TY, Y);
-  const int tiles_x = (X + AP_TX - 1) / AP_TX;
-  const int tx0 = bxi * ntx, tx1 = min(tx0 + ntx, tiles_x);
-  const bool rows_valid = !(oy > ay.hi || yend - 1 < ay.lo);
-  const int row0 = oy + ay.sh - 1 - AP_R;
-  const bool wide = X >= 8;  // a 16-byte load fits in a row
+  const int xend = min(ox + AP_TX, X), yend = min(ty1 * AM_TY, Y);
+  if (ox > ax.hi || xend - 1 < ax.lo || ty0 * AM_TY > ay.hi || yend - 1 < ay.lo) {
+    // no output of this workgroup has its source inside the image
+    const int w = xend - ox, h = yend - ty0 * AM_TY;
+    for (int i = tid; i < w * h; i += 256) po[(size_t)(ty0 * AM_TY + i / w) * X + ox + i % w] = 0;
+    return;
+  }
+  const int first = ox + ax.sh - 1 - AP_R;       // source column of staged column 0
+  const bool wide = X >= 8;                      // a 16-byte load fits in a row
+  const bool cols_inside = wide && first >= 0 && first + AP_TW <= X;
 
-  // this thread's staged vectors: (row, vector) are the same for every tile of the run
-  size_t rowoff[NV];
-  int v8[NV], lds_off[NV];
+  // this thread's staged vectors: (row in the step, vector) never change
+  int cl[NV], col0[NV], lds_off[NV], rr[NV];
 #pragma unroll
   for (int jv = 0; jv < NV; ++jv) {
-    int i = min(tid + jv * 256, NVEC - 1);       // clamped, so every load is unconditional
-    int r = i / (AP_TW / 8), v = i - r * (AP_TW / 8);
-    int yy = row0 + r;
-    if (yy < 0 || yy >= Y) yy = rows_valid ? reflect101_idx(yy, Y) : 0;
-    rowoff[jv] = (size_t)yy * X;
-    v8[jv] = 8 * v;
-    lds_off[jv] = r * (AP_PITCH / 8) + v;
+    const int i = tid + jv * 256;
+    const int r = i / VPR, v = i - r * VPR;
+    rr[jv] = r;
+    col0[jv] = first + 8 * v;
+    cl[jv] = min(max(col0[jv], 0), X - 8);
+    lds_off[jv] = r * LP + v;
   }
-  u32x4 q[NV];  // kept opaque so that the loads stay in flight until the tile is staged
-  auto geom = [&](int tx, int& first, bool& valid) {
-    const int ox = tx * AP_TX;
-    first = ox + ax.sh - 1 - AP_R;
-    valid = rows_valid && !(ox > ax.hi || min(ox + AP_TX, X) - 1 < ax.lo);
+  u32x4 q[NV];  // kept opaque so that the loads stay in flight until the rows are staged
+  auto row_off = [&](int yy, bool inside) -> size_t {
+    if (!inside) yy = reflect_near(yy, Y);
+    return (size_t)yy * X;
   };
-  auto preload = [&](int first) {  // vectors that stick out of the row are re-read element-wise when staged
+  auto border_vec = [&](size_t ro, int c0) {     // image border: mirrored scalar loads
+    unsigned e[8];
 #pragma unroll
-    for (int jv = 0; jv < NV; ++jv) {
-#ifdef IAP_AP_NOLOAD
-      const int cl = 0 * first;
-#else
-      const int cl = min(max(first + v8[jv], 0), X - 8);
-#endif
-      q[jv] = *reinterpret_cast<const u32x4_px*>(p + rowoff[jv] + cl);
-    }
+    for (int k = 0; k < 8; ++k) e[k] = p[ro + reflect_near(c0 + k, X)];
+    return (u32x4){e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
   };
-  auto stage = [&](int first) {  // the source tile as raw u16 (its readers convert)
-    if (wide && first >= 0 && first + AP_TW <= X) {  // uniform: every staged vector lies inside the row
+  auto preload = [&](int src0) {                 // AM_TY rows from source row src0 on
+    const bool inside = src0 >= 0 && src0 + AM_TY <= Y;
 #pragma unroll
-      for (int jv = 0; jv < NV; ++jv)
-        if (tid + jv * 256 < NVEC) tile[lds_off[jv]] = q[jv];
+    for (int jv = 0; jv < NV; ++jv)
+      q[jv] = *reinterpret_cast<const u32x4_px*>(p + row_off(src0 + rr[jv], inside) + cl[jv]);
+  };
+  auto stage = [&](int src0) {
+    if (cols_inside) {
+#pragma unroll
+      for (int jv = 0; jv < NV; ++jv) tile[lds_off[jv]] = q[jv];
       return;
     }
+    const bool inside = src0 >= 0 && src0 + AM_TY <= Y;
+    // the mirrored columns are the same at every step; worked out here each time (an opaque zero keeps
+    // them from being hoisted), they do not hold registers through the interior strips' loop
+    int zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
 #pragma unroll
     for (int jv = 0; jv < NV; ++jv) {
-      if (tid + jv * 256 < NVEC) {
-        const int col0 = first + v8[jv];
-        u32x4 w8;
-        if (wide && col0 >= 0 && col0 + 8 <= X) {
-          w8 = q[jv];
-        } else {  // image border: mirrored scalar loads
-          unsigned e[8];
-#pragma unroll
-          for (int k = 0; k < 8; ++k) e[k] = p[rowoff[jv] + reflect101_idx(col0 + k, X)];
-          w8 = (u32x4){e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
-        }
-        tile[lds_off[jv]] = w8;
-      }
+      u32x4 w8 = q[jv];
+      const int c0 = col0[jv] + zero;
+      if (!(wide && c0 >= 0 && c0 + 8 <= X)) w8 = border_vec(row_off(src0 + rr[jv], inside), c0);
+      tile[lds_off[jv]] = w8;
     }
   };
-  {
-    int first;
-    bool valid;
-    geom(tx0, first, valid);
-    if (valid) {
-      if (wide) preload(first);
-      stage(first);
+  // x pass over `nrows` staged rows -> colp rows jbase ..: one wave per run pair (m, m+4) when nrows = 64
+  auto xpass = [&](int nrows, int jbase) {
+    for (int i = tid; i < nrows * (AP_TX / 2 / AM_G); i += 256) {
+      const int m = i / nrows, r = i - m * nrows;
+      const u32x4* t = tile + r * LP + m;
+      u32x4 ra[5], rb[5];   // samples 0..21 (vectors 0..2) feed the upward sweep, 11..32 the downward one
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        ra[k] = t[k];
+        rb[k] = t[k + 4];
+      }
+      auto rest = [&] {
+#pragma unroll
+        for (int k = 3; k < 5; ++k) {
+          ra[k] = t[k];
+          rb[k] = t[k + 4];
+        }
+      };
+      auto smp = [&](int i) {            // sample i of both runs: u16 -> f32
+        const unsigned a = ra[i >> 3][(i >> 1) & 3], b = rb[i >> 3][(i >> 1) & 3];
+        return (i & 1) ? (v2f){(float)(a >> 16), (float)(b >> 16)} : (v2f){(float)(a & 0xffffu), (float)(b & 0xffffu)};
+      };
+      v2f res[AM_G];
+      if (ax.whole) {
+#pragma unroll
+        for (int k = 0; k < AM_G; ++k) res[k] = smp(AP_R + 1 + k);
+      } else {
+        spline_run2<AM_G>(smp, rest, ax.w, res);
+      }
+      v2f* d = colp + (AM_G * m) * AM_CP + jbase + r;
+#pragma unroll
+      for (int k = 0; k < AM_G; ++k) d[k * AM_CP] = res[k];
     }
+  };
+
+  // prologue: the 25 rows above the first step's new rows, staged and x-filtered on their own
+  {
+    const int src0 = ty0 * AM_TY + ay.sh - 1 - AP_R;
+    for (int i = tid; i < AM_HALO * VPR; i += 256) {
+      const int r = i / VPR, v = i - r * VPR;
+      const size_t ro = row_off(src0 + r, false);
+      const int c0 = first + 8 * v;
+      u32x4 w8;
+      if (wide && c0 >= 0 && c0 + 8 <= X) w8 = *reinterpret_cast<const u32x4_px*>(p + ro + c0);
+      else w8 = border_vec(ro, c0);
+      tile[r * LP + v] = w8;
+    }
+    if (wide) preload(src0 + AM_HALO);
+    __syncthreads();
+    xpass(AM_HALO, 0);
+    __syncthreads();
+    stage(src0 + AM_HALO);
+    if (ty0 + 1 < ty1 && wide) preload(src0 + AM_HALO + AM_TY);
   }
   AP_STAMP(0);
 
-  // Per tile: barrier A | issue the next tile's loads | x pass (tile -> colp) | barrier B | stage the
-  // next tile | y pass + stores.  The next tile is staged BEFORE this tile's stores are issued:
-  // waiting for its loads (vmcnt counts in order) then never waits for a store.
-  for (int tx = tx0; tx < tx1; ++tx) {
-    const int ox = tx * AP_TX;
-    int first, nfirst = 0;
-    bool valid, nvalid = false;
-    geom(tx, first, valid);
-    if (tx + 1 < tx1) geom(tx + 1, nfirst, nvalid);
-
-    if (!valid) {  // no output of this tile has its source inside the image: zeros
-      for (int i = tid; i < TY * AP_TX; i += 256) {
-        int r = i / AP_TX, c = i - r * AP_TX;
-        if (oy + r < Y && ox + c < X) po[(size_t)(oy + r) * X + ox + c] = 0;
-      }
-      if (nvalid) {  // `tile` is free: its last readers passed barrier B of an earlier tile
-        if (wide) preload(nfirst);
-        stage(nfirst);
-      }
-      continue;
-    }
-    __syncthreads();   // A: the staged tile is visible, colp is free
+  for (int ty = ty0; ty < ty1; ++ty) {
+    const int oy = ty * AM_TY;
+    const int nsrc = oy + AM_TY + ay.sh + AP_R + 2;   // first new source row of the next step
+    const bool more = ty + 1 < ty1;
+    __syncthreads();   // A: staged rows and the carried rows are visible; colp rows 25.. are free
     AP_STAMP(1);
-    if (nvalid && wide) preload(nfirst);
-
-    // ---- x pass: TH rows x 4 runs of 16 outputs; lanes run along rows; result stored transposed
-    for (int i = tid; i < TH * (AP_TX / AP_XG); i += 256) {
-      const int m = i / TH, r = i - m * TH;
-      const u32x4* t = tile + r * (AP_PITCH / 8) + (AP_XG / 8) * m;
-      float s[XS];
-#pragma unroll
-      for (int k = 0; k < XS / 8; ++k) {
-        const u32x4 v8r = t[k];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          s[8 * k + 2 * e] = (float)(v8r[e] & 0xffffu);
-          s[8 * k + 2 * e + 1] = (float)(v8r[e] >> 16);
-        }
-      }
-      float res[AP_XG];
-      if (ax.whole) {
-#pragma unroll
-        for (int k = 0; k < AP_XG; ++k) res[k] = s[AP_R + 1 + k];
-      } else {
-        spline_run<AP_XG>(s, ax.w, res);
-      }
-      float* d = colp + (AP_XG * m) * CP + r;
-#pragma unroll
-      for (int k = 0; k < AP_XG; ++k) d[k * CP] = res[k];
-    }
+    xpass(AM_TY, AM_HALO);
     AP_STAMP(2);
-    __syncthreads();   // B: colp is visible, the tile is free
+    __syncthreads();   // B: colp is complete, the tile is free
     AP_STAMP(3);
-    if (nvalid) stage(nfirst);
+    if (more) stage(nsrc);
+    // the loads of the step after that fly during this y pass and the next x pass; they are older than
+    // the stores below, so waiting for them (vmcnt counts in order) does not wait for a store
+    if (ty + 2 < ty1 && wide) preload(nsrc + AM_TY);
     AP_STAMP(4);
-
-    // ---- y pass: one column per lane, YG consecutive rows per thread, stored straight to the
-    // plane (a wave writes 64 neighbouring pixels of one row per store)
+    // ---- y pass: a column pair per lane, 8 rows per thread; stores go straight to the plane
     {
-      const int c = tid & 63, y0 = (tid >> 6) * YG;
-      const float4* t = reinterpret_cast<const float4*>(colp + c * CP + y0);
-      float s[YS];
+      const int pr = tid & 31, y0 = (tid >> 5) * AM_G;
+      const float4* t = reinterpret_cast<const float4*>(colp + pr * AM_CP + y0);
+      float4 tv[17];   // rows 0..21 feed the upward sweep, rows 11..32 the downward one
 #pragma unroll
-      for (int k = 0; k < YS / 4; ++k) {
-        const float4 v4 = t[k];
-        s[4 * k] = v4.x; s[4 * k + 1] = v4.y; s[4 * k + 2] = v4.z; s[4 * k + 3] = v4.w;
-      }
-      float res[YG];
+      for (int k = 0; k < 11; ++k) tv[k] = t[k];
+      auto rest = [&] {
+#pragma unroll
+        for (int k = 11; k < 17; ++k) tv[k] = t[k];
+      };
+      auto smp = [&](int i) { return (i & 1) ? (v2f){tv[i >> 1].z, tv[i >> 1].w} : (v2f){tv[i >> 1].x, tv[i >> 1].y}; };
+      v2f res[AM_G];
       if (ay.whole) {
 #pragma unroll
-        for (int k = 0; k < YG; ++k) res[k] = s[AP_R + 1 + k];
+        for (int k = 0; k < AM_G; ++k) res[k] = smp(AP_R + 1 + k);
       } else {
-        spline_run<YG>(s, ay.w, res);
+        spline_run2<AM_G>(smp, rest, ay.w, res);
       }
-      const int xx = ox + c;
-      const bool xin = xx >= ax.lo && xx <= ax.hi;
-      // uniform: every output of the tile has its source inside the image and lies inside the plane
-      const bool interior = ox >= ax.lo && ox + AP_TX - 1 <= ax.hi && oy >= ay.lo && oy + TY - 1 <= ay.hi &&
-                            ox + AP_TX <= X && oy + TY <= Y;
-      if (interior) {
-        uint16_t* o0 = po + (size_t)(oy + y0) * X + xx;
+      const int xa = ox + pr, xb = xa + 32;
+      const bool interior = ox >= ax.lo && ox + AP_TX - 1 <= ax.hi && oy >= ay.lo && oy + AM_TY - 1 <= ay.hi &&
+                            ox + AP_TX <= X && oy + AM_TY <= Y;
+      if (interior) {   // uniform: every output has its source inside the image and lies inside the plane
+        uint16_t* o0 = po + (size_t)(oy + y0) * X + xa;
 #pragma unroll
-        for (int k = 0; k < YG; ++k)   // clamp, then truncation toward zero; written once, not re-read here
-          __builtin_nontemporal_store((uint16_t)(unsigned)__builtin_amdgcn_fmed3f(res[k], 0.f, 65535.f), o0 + (size_t)k * X);
-      } else if (xx < X) {
+        for (int k = 0; k < AM_G; ++k) {   // clamp, then truncation toward zero; written once, not re-read here
+          __builtin_nontemporal_store((uint16_t)(unsigned)__builtin_amdgcn_fmed3f(res[k].x, 0.f, 65535.f), o0 + (size_t)k * X);
+          __builtin_nontemporal_store((uint16_t)(unsigned)__builtin_amdgcn_fmed3f(res[k].y, 0.f, 65535.f), o0 + (size_t)k * X + 32);
+        }
+      } else {
+        const bool ain = xa >= ax.lo && xa <= ax.hi, bin = xb >= ax.lo && xb <= ax.hi;
 #pragma unroll
-        for (int k = 0; k < YG; ++k) {
+        for (int k = 0; k < AM_G; ++k) {
           const int yy = oy + y0 + k;
-          const bool inside = xin && yy >= ay.lo && yy <= ay.hi;
-          const float v = inside ? fminf(fmaxf(res[k], 0.f), 65535.f) : 0.f;
-          if (yy < Y) __builtin_nontemporal_store((uint16_t)(unsigned)v, po + (size_t)yy * X + xx);   // truncation toward zero; written once, not re-read here
+          const bool yin = yy >= ay.lo && yy <= ay.hi;
+          if (yy < Y) {
+            const float va = ain && yin ? fminf(fmaxf(res[k].x, 0.f), 65535.f) : 0.f;
+            const float vb = bin && yin ? fminf(fmaxf(res[k].y, 0.f), 65535.f) : 0.f;
+            if (xa < X) __builtin_nontemporal_store((uint16_t)(unsigned)va, po + (size_t)yy * X + xa);
+            if (xb < X) __builtin_nontemporal_store((uint16_t)(unsigned)vb, po + (size_t)yy * X + xb);
+          }
         }
       }
     }
     AP_STAMP(5);
+    if (more) {
+      __syncthreads();   // C: the y pass has read colp; carry rows 64..89 up to rows 0..25
+      for (int i = tid; i < (AP_TX / 2) * 13; i += 256) {
+        const int pr = i / 13, k = i - pr * 13;
+        float4* c = reinterpret_cast<float4*>(colp + pr * AM_CP);
+        c[k] = c[AM_TY / 2 + k];
+      }
+    }
+    AP_STAMP(6);
   }
 #ifdef IAP_AP_STAMPS
   if (tid == 0)
-    for (int i = 0; i < 6; ++i) atomicAdd(&g_ap_stamps[i], (unsigned long long)t_acc[i]);
+    for (int i = 0; i < 7; ++i) atomicAdd(&g_ap_stamps[i], (unsigned long long)t_acc[i]);
 #endif
 }
 
@@ -1284,13 +1336,13 @@ static int launch_mip(const uint16_t* in, long long in_stride, uint16_t* out, lo
 
 static int launch_apply(const uint16_t* in, uint16_t* out, long long n_frames, long long ppf, int Y, int X,
                         const double* shifts, hipStream_t st) {
-  constexpr int TY = 32;
-  const int tiles_x = (X + AP_TX - 1) / AP_TX;
-  // each workgroup walks `ntx` tiles along x, prefetching the next tile while it filters this one
-  int ntx = 16;
-  if (const char* e = getenv("IAP_APPLY_NTX")) ntx = atoi(e) > 0 ? atoi(e) : ntx;
-  while (ntx > 1 && (long long)((tiles_x + ntx - 1) / ntx) * ((Y + TY - 1) / TY) * ppf * n_frames < 8192) ntx >>= 1;
-  dim3 grid((tiles_x + ntx - 1) / ntx, (Y + TY - 1) / TY, 1);
+  const int tiles_x = (X + AP_TX - 1) / AP_TX, tiles_y = (Y + AM_TY - 1) / AM_TY;
+  // each workgroup walks `nty` steps down its strip.  Long walks amortise the 25-row lead-in, short ones keep
+  // neighbouring strips close enough in time for the columns they share to be served by L2: 8 measured best
+  int nty = 8;
+  if (const char* e = getenv("IAP_APPLY_NTY")) nty = atoi(e) > 0 ? atoi(e) : nty;
+  while (nty > 1 && (long long)tiles_x * ((tiles_y + nty - 1) / nty) * ppf * n_frames < 8192) nty >>= 1;
+  dim3 grid(tiles_x, (tiles_y + nty - 1) / nty, 1);
   // blockIdx.z is limited to 65535: chunk by whole frames
   long long fpc = 65535 / ppf;
   if (fpc < 1) return IAP_E_UNSUPPORTED;
@@ -1298,8 +1350,8 @@ static int launch_apply(const uint16_t* in, uint16_t* out, long long n_frames, l
     long long nf = n_frames - f0 < fpc ? n_frames - f0 : fpc;
     grid.z = (unsigned)(nf * ppf);
     ProfScope ps_(K_APPLY, st);
-    hipLaunchKernelGGL(apply_shift_kernel<TY>, grid, dim3(256), 0, st, in + (size_t)f0 * ppf * Y * X,
-                       out + (size_t)f0 * ppf * Y * X, ppf, Y, X, shifts + 2 * f0, ntx);
+    hipLaunchKernelGGL(apply_shift_kernel, grid, dim3(256), 0, st, in + (size_t)f0 * ppf * Y * X,
+                       out + (size_t)f0 * ppf * Y * X, ppf, Y, X, shifts + 2 * f0, nty);
   }
   IAP_LAUNCH_CHECK();
   return IAP_OK;
