@@ -5,14 +5,15 @@
 // Estimate, per moving plane (all on device, no host round trip):
 //   K1 rows_r2c      u16 rows -> half spectrum, two real rows per complex FFT (LDS Stockham)
 //   K2 cols_xpower   column FFT, * conj-multiply with the reference spectrum (DC zeroed,
-//                    optional phase normalisation), write P, inverse column FFT in the same
-//                    LDS tile, write back in place
+//                    optional phase normalisation), inverse column FFT in the same LDS tile,
+//                    write back in place: Q[y][v], spatial along y, spectral along x
 //   K3 rows_c2r_argmax  inverse row FFT + wave-shuffle / LDS arg-max (correlation surface is
 //                    never written to HBM)
 //   K4 coarse_finish    arg-max over the per-workgroup partials -> signed integer shift
-//   K5 upsample_tables / upsample_partial  matrix-DFT of P on a 15x15 grid of 0.1 px offsets,
-//                    +-m symmetric form, per-chunk partials (the Nyquist column rides in the
-//                    table kernel)
+//   K5 upsample_tables / upsample_partial  matrix-DFT of the cross-power spectrum on a 15x15 grid of
+//                    0.1 px offsets, evaluated from Q (the buffer K3 reads anyway, so the spectrum
+//                    itself is never written): periodic-sinc weights along y, +-m symmetric phases
+//                    along x, per-chunk partials (the Nyquist column rides in the table kernel)
 //   K6 upsample_finish  sum partials, arg-max, parabolic vertex -> (dy, dx) as f64
 // Apply: apply_shift_kernel -- separable cubic B-spline shift = scipy.ndimage.shift(order=3):
 // mirror-boundary prefilter as two one-multiply recursions started from 12 explicit taps
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_r2c_kernel
 //         moving frame re-reads it tile by tile: contiguous 16-byte-per-lane reads instead of
 //         32-byte row pieces.
 // mode 1: forward FFT, P = G * conj(F) * scale (DC = 0, optional /|P|) with G = Gref (tile-major),
-//         store P to R (row-major, if R), inverse FFT, store back to F in place.
+//         inverse FFT, store back to F in place (R unused).
 template <int N>
 __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_kernel(
     cf* __restrict__ F, long long F_stride, const cf* __restrict__ Gref, cf* __restrict__ R, long long R_stride,
@@ -250,13 +251,11 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_kerne
   __syncthreads();
   fft_lds<N, -1, Gm::CE>(s, j, tw);
   if (mode == 1) {
-    cf* Rf = R ? R + (size_t)frame * R_stride : nullptr;
 #pragma unroll 4
     for (int m = 0; m < Gm::CE / 2; ++m) {
       const int idx = tid + m * NTH;
       const int pc = idx % HP, u = idx / HP;
       const float4 f2 = *reinterpret_cast<const float4*>(Gref + (size_t)v0 * N + 2 * idx);   // tile-major: [u][cc]
-      cf pp[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const cf g = lds_c[(2 * pc + h) * Gm::CS + padi(u)];
@@ -270,9 +269,7 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_kerne
         }
         if (u == 0 && v0 + 2 * pc + h == 0) p = make_float2(0.f, 0.f);
         lds_c[(2 * pc + h) * Gm::CS + padi(u)] = p;
-        pp[h] = p;
       }
-      if (Rf) *reinterpret_cast<float4*>(Rf + (size_t)u * Wp + v0 + 2 * pc) = make_float4(pp[0].x, pp[0].y, pp[1].x, pp[1].y);
     }
     __syncthreads();
     fft_lds<N, +1, Gm::CE>(s, j, tw);
@@ -389,19 +386,25 @@ __global__ __launch_bounds__(256) void coarse_finish_kernel(const float* __restr
 }
 
 // K5 ---------------------------------------------------------------------------------------
-// Matrix-DFT of the cross-power spectrum on the 15 x 15 grid of 0.1 px offsets round the coarse
-// peak:  V[j][k] = Re sum_{u,v} w_v R[u][v] ey[u][j] ex[v][k],  ey[u][7 +- m] = base_u (a_m +- i b_m)
-// with base_u = exp(2 pi i fu sy / Py) and a_m + i b_m = exp(2 pi i fu 0.1 m / Py) (same along x).
-// The +-m symmetry halves the work: with c = R base, A_m = sum c a_m and B_m = sum c b_m are
-// complex-times-real sums and T[7 +- m] = A_m +- i B_m.
+// Matrix-DFT of the cross-power spectrum R on the 15 x 15 grid of 0.1 px offsets round the coarse
+// peak:  V[j][k] = Re sum_{u,v} w_v R[u][v] ey[u][j] ex[v][k],  ey[u][j] = exp(2 pi i fu y'_j / Py),
+// y'_j = sy + 0.1 (j - 7), fu the signed frequency of row u (the Nyquist row counts as -Py/2), the
+// same along x.  R itself is never stored: the kernels read Q[y][v] = sum_u R[u][v] exp(2 pi i u y / Py),
+// which K2 leaves for K3, and use
+//   T[j][v] = sum_u R[u][v] ey[u][j] = sum_y Q[y][v] K(y'_j - y),
+//   K(t) = 1/Py sum_fu exp(2 pi i fu t / Py) = Ks(t) + exp(-i pi t) / Py,
+//   Ks(t) = sin(pi t (Py-1)/Py) / (Py sin(pi t / Py))          (real: the frequencies |fu| < Py/2)
+// so a row contributes 15 real weights Ks(y'_j - y) and the term of the Nyquist row,
+// exp(-i pi y'_j) * sum_y (-1)^y Q[y][v] / Py, rides as a 16th real weight.  Along x the +-m symmetry
+// halves the work: ex[v][7 +- m] = base_v (a_m +- i b_m), a_m + i b_m = exp(2 pi i fv 0.1 m / Px).
 constexpr int UP_N = 15;       // grid points per axis: offsets -0.7 .. 0.7
 constexpr int UP_HALF = 7;
 constexpr float UP_STEP = 0.1f;
 constexpr int UP_UB_MIN = 64;  // fewest spectrum rows a workgroup takes
-constexpr int UP_YS = 16;      // floats per row record   {base.x, base.y, a1..a7, b1..b7}  (one 64-byte scalar load)
+constexpr int UP_YS = 16;      // floats per row record   {Ks(y'_0 - y) .. Ks(y'_14 - y), (-1)^y / Py}  (one 64-byte scalar load)
 constexpr int UP_XS = 20;      // floats per column record {w base.x, w base.y, 0, 0 | 1, a1..a7 | b1..b7, 0}
 constexpr int UP_NV = UP_N * UP_N;  // 225 grid values
-constexpr int UP_NQ = 32;      // floats per Nyquist-column partial: {ctr, A1..A7, B1..B7} as complex pairs, padded
+constexpr int UP_NQ = 32;      // floats per Nyquist-column partial: the 16 weighted row sums as complex pairs
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ cf unit_phase(int freq, int ishift, int n, float frac_shift) {
@@ -417,43 +420,69 @@ __device__ __forceinline__ cf unit_phase(int freq, int ishift, int n, float frac
 __device__ long long* g_up_stamps;
 #endif
 
-// T[j] (j = 0..14) from the centre sum and the A/B sums:  T[7] = ctr,  T[7 +- m] = A_m +- i B_m
-__device__ __forceinline__ v2f up_combine(int j, v2f ctr, const v2f* A, const v2f* B) {
-  const int m = j >= UP_HALF ? j - UP_HALF : UP_HALF - j;
-  if (m == 0) return ctr;
-  if (j > UP_HALF) return (v2f){A[m - 1].x - B[m - 1].y, A[m - 1].y + B[m - 1].x};
-  return (v2f){A[m - 1].x + B[m - 1].y, A[m - 1].y - B[m - 1].x};
+// Ks(t) for t = n + f_j (n integer, f_j = 0.1 (j - 7)), in double.  With alpha = pi n / Py,
+// gamma_j = pi f_j (1 - 1/Py) and delta_j = pi f_j / Py:
+//   Ks = (-1)^n sin(gamma_j - alpha) / (Py sin(alpha + delta_j)),
+// so a row costs one sincospi; k = {sin gamma_j, cos gamma_j, sin delta_j, cos delta_j}.
+__device__ __forceinline__ void row_weight_consts(int j, int Py, double* k) {
+  const double f = 0.1 * (double)(j - UP_HALF);
+  sincospi(f * (1.0 - 1.0 / (double)Py), &k[0], &k[1]);
+  sincospi(f / (double)Py, &k[2], &k[3]);
+}
+__device__ __forceinline__ float row_weight(double sa, double ca, bool odd, const double* k, int Py) {
+  const double den = sa * k[3] + ca * k[2];
+  if (den == 0.0) return (float)((double)(Py - 1) / (double)Py);   // t = 0 (mod Py)
+  const double num = k[0] * ca - k[1] * sa;
+  return (float)((odd ? -num : num) / ((double)Py * den));
 }
 
-// Row and column records of every frame of the batch (the coarse shift enters through base
-// only).  The threads that build row records also sum the Nyquist column v = Px/2, which the
-// main kernel's power-of-two column split leaves out: one partial {ctr, A, B} per workgroup.
+// T[j] (j = 0..14) from the weighted row sums: acc[j] + exp(-i pi y'_j) acc[15], y'_j = sy + 0.1 (j - 7)
+__device__ __forceinline__ v2f up_row_sum(int j, int sy, const v2f* acc) {
+  // cos, sin of pi m / 10, m = 0..7
+  constexpr float C[8] = {1.f, 0.95105651629515357f, 0.80901699437494742f, 0.58778525229247313f,
+                          0.30901699437494742f, 0.f, -0.30901699437494742f, -0.58778525229247313f};
+  constexpr float S[8] = {0.f, 0.30901699437494742f, 0.58778525229247313f, 0.80901699437494742f,
+                          0.95105651629515357f, 1.f, 0.95105651629515357f, 0.80901699437494742f};
+  const int m = j >= UP_HALF ? j - UP_HALF : UP_HALF - j;
+  const float sg = (sy & 1) ? -1.f : 1.f;
+  const float pc = sg * C[m], ps = (j >= UP_HALF ? -sg : sg) * S[m];   // exp(-i pi y') = (-1)^sy (cos - i sin)(pi (j-7)/10)
+  const v2f n = acc[UP_N];
+  return (v2f){acc[j].x + (n.x * pc - n.y * ps), acc[j].y + (n.x * ps + n.y * pc)};
+}
+
+// Row and column records of every frame of the batch (the coarse shift enters the row weights
+// and the column base).  The threads that build row records also sum the Nyquist column
+// v = Px/2, which the main kernel's power-of-two column split leaves out: one partial (16 weighted
+// row sums) per workgroup.
 __global__ __launch_bounds__(256) void upsample_tables_kernel(int Py, int Px, int Wp, const int2* __restrict__ coarse,
-                                                              const cf* __restrict__ R, long long R_stride,
+                                                              const cf* __restrict__ Q, long long Q_stride,
                                                               float* __restrict__ yrec, float* __restrict__ xrec,
                                                               float* __restrict__ nyq, int nyb) {
   __shared__ float wsum[4][UP_NQ];
+  __shared__ double wk[UP_N][4];
   const int frame = blockIdx.y;
   const int tid = threadIdx.x;
   const int i = blockIdx.x * 256 + tid;
   const int2 cs = coarse[frame];
-  v2f ctr = {0.f, 0.f}, A[UP_HALF], B[UP_HALF];
+  if (tid < UP_N) row_weight_consts(tid, Py, wk[tid]);
+  __syncthreads();
+  v2f acc[UP_N + 1];
 #pragma unroll
-  for (int m = 0; m < UP_HALF; ++m) A[m] = B[m] = (v2f){0.f, 0.f};
+  for (int j = 0; j <= UP_N; ++j) acc[j] = (v2f){0.f, 0.f};
   if (i < Py) {
-    const int fu = i < Py / 2 ? i : i - Py;
-    const cf r = R[(size_t)frame * R_stride + (size_t)i * Wp + Px / 2];
-    float* o = yrec + ((size_t)frame * Py + i) * UP_YS;
-    const cf bs = unit_phase(fu, cs.x, Py, 0.f);
-    o[0] = bs.x; o[1] = bs.y;
-    ctr = (v2f){fmaf(r.x, bs.x, -(r.y * bs.y)), fmaf(r.x, bs.y, r.y * bs.x)};
+    const cf q = Q[(size_t)frame * Q_stride + (size_t)i * Wp + Px / 2];
+    const int n = cs.x - i;
+    double sa, ca;
+    sincospi((double)n / (double)Py, &sa, &ca);
+    float wgt[UP_YS];
 #pragma unroll
-    for (int m = 1; m <= UP_HALF; ++m) {
-      const cf e = unit_phase(fu, 0, Py, (float)m * UP_STEP);
-      o[1 + m] = e.x; o[1 + UP_HALF + m] = e.y;
-      A[m - 1] = (v2f){ctr.x * e.x, ctr.y * e.x};
-      B[m - 1] = (v2f){ctr.x * e.y, ctr.y * e.y};
-    }
+    for (int j = 0; j < UP_N; ++j) wgt[j] = row_weight(sa, ca, n & 1, wk[j], Py);
+    wgt[UP_N] = ((i & 1) ? -1.f : 1.f) / (float)Py;
+    float4* o = reinterpret_cast<float4*>(yrec + ((size_t)frame * Py + i) * UP_YS);
+#pragma unroll
+    for (int k = 0; k < UP_YS / 4; ++k) o[k] = make_float4(wgt[4 * k], wgt[4 * k + 1], wgt[4 * k + 2], wgt[4 * k + 3]);
+#pragma unroll
+    for (int j = 0; j <= UP_N; ++j) acc[j] = (v2f){q.x * wgt[j], q.y * wgt[j]};
   } else if (i - Py < Wp) {
     const int v = i - Py;
     const int fv = v < Px / 2 ? v : v - Px;
@@ -467,18 +496,16 @@ __global__ __launch_bounds__(256) void upsample_tables_kernel(int Py, int Px, in
       o[4 + m] = e.x; o[11 + m] = e.y;
     }
   }
-  if ((int)blockIdx.x < nyb) {  // uniform: this workgroup holds spectrum rows
+  if ((int)blockIdx.x < nyb) {  // uniform: this workgroup holds rows
 #pragma unroll
-    for (int q = 0; q < 2 * UP_N; ++q) {
-      float x = q < 2 ? (q ? ctr.y : ctr.x)
-                      : (q < 16 ? ((q & 1) ? A[(q - 2) >> 1].y : A[(q - 2) >> 1].x)
-                                : ((q & 1) ? B[(q - 16) >> 1].y : B[(q - 16) >> 1].x));
+    for (int q = 0; q < UP_NQ; ++q) {
+      float x = (q & 1) ? acc[q >> 1].y : acc[q >> 1].x;
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) x += __shfl_down(x, d, 64);
       if ((tid & 63) == 0) wsum[tid >> 6][q] = x;
     }
     __syncthreads();
-    if (tid < 2 * UP_N)
+    if (tid < UP_NQ)
       nyq[((size_t)frame * nyb + blockIdx.x) * UP_NQ + tid] =
           (wsum[0][tid] + wsum[1][tid]) + (wsum[2][tid] + wsum[3][tid]);
   }
@@ -494,13 +521,14 @@ __device__ __forceinline__ float up_grid_value(const float* pq, int j, int k) {
   return k > UP_HALF ? pv - qv : pv + qv;
 }
 
-// One workgroup: 512 spectrum columns (two per thread, v < Px/2) x ub rows.  Row records are
+// One workgroup: 512 columns (two per thread, v < Px/2) x ub rows of Q.  Row records are
 // wave-uniform and arrive through one 64-byte scalar load per row.  The column sums T[j][v],
 // multiplied by the column base, are then contracted over v in LDS: a lane owns a 4 x 4 block of
 // the P (Re T x a) or Q (Im T x b) sums for every fourth column of its wave's 64, so that two
 // 16-byte LDS reads feed 16 FMAs; lanes, then waves, are summed in fixed order (deterministic).
 __global__ __launch_bounds__(256) void upsample_partial_kernel(const cf* __restrict__ R, long long R_stride, int Wp,
                                                                int Py, int Px, int ncg, int ub,
+                                                               const int2* __restrict__ coarse,
                                                                const float* __restrict__ yrec,
                                                                const float* __restrict__ xrec,
                                                                float* __restrict__ part, int slots) {
@@ -520,13 +548,11 @@ __global__ __launch_bounds__(256) void upsample_partial_kernel(const cf* __restr
   bool ok[2];
 #pragma unroll
   for (int c = 0; c < 2; ++c) { vcol[c] = cg * 512 + c * 256 + tid; ok[c] = vcol[c] < half; }
-  v2f ctr[2], A[2][UP_HALF], B[2][UP_HALF];
+  v2f acc[2][UP_N + 1];   // the 15 weighted row sums and the Nyquist-row sum, per column
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    ctr[c] = (v2f){0.f, 0.f};
+  for (int c = 0; c < 2; ++c)
 #pragma unroll
-    for (int m = 0; m < UP_HALF; ++m) A[c][m] = B[c][m] = (v2f){0.f, 0.f};
-  }
+    for (int j = 0; j <= UP_N; ++j) acc[c][j] = (v2f){0.f, 0.f};
   const cf* Rp[2];
 #pragma unroll
   for (int c = 0; c < 2; ++c) Rp[c] = R + (size_t)frame * R_stride + (size_t)u0 * Wp + (ok[c] ? vcol[c] : 0);
@@ -546,18 +572,11 @@ __global__ __launch_bounds__(256) void upsample_partial_kernel(const cf* __restr
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       const float* __restrict__ rec = yr + (ul + i) * UP_YS;
-      const float bx = rec[0], by = rec[1];
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        const float t1 = r[c][i].y * by, t2 = r[c][i].y * bx;
-        const v2f cc = {fmaf(r[c][i].x, bx, -t1), fmaf(r[c][i].x, by, t2)};
-        ctr[c] += cc;
+        const v2f q = {r[c][i].x, r[c][i].y};
 #pragma unroll
-        for (int m = 0; m < UP_HALF; ++m) {
-          const float am = rec[2 + m], bm = rec[2 + UP_HALF + m];
-          A[c][m] = __builtin_elementwise_fma(cc, (v2f){am, am}, A[c][m]);
-          B[c][m] = __builtin_elementwise_fma(cc, (v2f){bm, bm}, B[c][m]);
-        }
+        for (int j = 0; j <= UP_N; ++j) acc[c][j] = __builtin_elementwise_fma(q, (v2f){rec[j], rec[j]}, acc[c][j]);
       }
     }
 #pragma unroll
@@ -569,6 +588,7 @@ __global__ __launch_bounds__(256) void upsample_partial_kernel(const cf* __restr
   const long long t_main = wall_clock64();
 #endif
   // contraction over columns
+  const int sy = coarse[frame].x;
   const int wv = tid >> 6, lane = tid & 63, vsub = lane >> 4, blk = lane & 15;
   const int isq = blk >> 3, j0 = ((blk & 7) >> 1) * 4, m0 = (blk & 1) * 4;
   float sum[4][4];
@@ -589,7 +609,7 @@ __global__ __launch_bounds__(256) void upsample_partial_kernel(const cf* __restr
       float tre[16], tim[16];
 #pragma unroll
       for (int j = 0; j < UP_N; ++j) {
-        const v2f t = up_combine(j, ctr[c], A[c], B[c]);
+        const v2f t = up_row_sum(j, sy, acc[c]);
         tre[j] = fmaf(t.x, bx, -(t.y * by));
         tim[j] = fmaf(t.x, by, t.y * bx);
       }
@@ -672,10 +692,10 @@ __global__ __launch_bounds__(256) void upsample_finish_kernel(const float* __res
       for (int q = 0; q < 8; ++q) s += t[q];
     }
     for (; c < nchunks; ++c) s += pp[(size_t)c * (UP_N * UP_N)];
-    {  // the Nyquist column (weight 1): single-term P and Q sums
+    {  // the Nyquist column (weight 1): its row sums come from the table kernel; single-term P and Q sums
       const int j = tid / UP_N, k = tid - j * UP_N;
       const float* xr = xrec + ((size_t)frame * Wp + Px / 2) * UP_XS;
-      const v2f t = up_combine(j, (v2f){nq[0], nq[1]}, (const v2f*)&nq[2], (const v2f*)&nq[16]);
+      const v2f t = up_row_sum(j, coarse[frame].x, (const v2f*)nq);
       const float cx = fmaf(t.x, xr[0], -(t.y * xr[1])), cy = fmaf(t.x, xr[1], t.y * xr[0]);
       const int m = k >= UP_HALF ? k - UP_HALF : UP_HALF - k;
       const float pv = cx * xr[4 + m], qv = m ? cy * xr[11 + m] : 0.f;
@@ -1139,7 +1159,7 @@ static bool make_plan(int Y, int X, RegPlan& p) {
 }
 
 struct RegWs {
-  cf *tw_x, *tw_y, *refspec, *F, *R;
+  cf *tw_x, *tw_y, *refspec, *F;
   float* pval;
   int* pidx;
   int2* coarse;
@@ -1158,7 +1178,7 @@ static size_t reg_fixed_bytes(const RegPlan& p) {
          align256((size_t)p.Y * p.X * 4) + 1024;
 }
 static size_t reg_frame_bytes(const RegPlan& p, int Z) {
-  size_t b = 2 * align256(p.spec * 8) + 2 * align256((size_t)p.row_blocks * 4) + 256 +
+  size_t b = align256(p.spec * 8) + 2 * align256((size_t)p.row_blocks * 4) + 256 +
              align256((size_t)p.ncg * p.nuc * UP_NV * 4) + align256((size_t)p.Py * UP_YS * 4) +
              align256((size_t)p.Wp * UP_XS * 4) + align256((size_t)((p.Py + 255) / 256) * UP_NQ * 4);
   if (Z > 1) b += align256((size_t)p.Y * p.X * 2);
@@ -1183,7 +1203,6 @@ static bool carve(void* ws, size_t bytes, const RegPlan& p, int Z, RegWs& w) {
   w.mip_ref = (uint16_t*)take((size_t)p.Y * p.X * 2);
   w.sum = (uint32_t*)take((size_t)p.Y * p.X * 4);
   w.F = (cf*)take((size_t)batch * align256(p.spec * 8));
-  w.R = (cf*)take((size_t)batch * align256(p.spec * 8));
   w.pval = (float*)take((size_t)batch * p.row_blocks * 4);
   w.pidx = (int*)take((size_t)batch * p.row_blocks * 4);
   w.coarse = (int2*)take((size_t)batch * 8);
@@ -1293,8 +1312,7 @@ static int reg_estimate_batch(const RegPlan& p, RegWs& w, const uint16_t* mov, l
   const bool up = flags & IAP_REG_UPSAMPLE;
   int rc = launch_rows_r2c(p, mov, 0, mov_stride, 1.0f, w.F, fs, n, w.tw_x, st);
   if (rc) return rc;
-  rc = launch_cols(p, w.F, fs, w.refspec, up ? w.R : nullptr, fs, n, w.tw_y, 1, (flags & IAP_REG_NORMALIZE) ? 1 : 0,
-                   st);
+  rc = launch_cols(p, w.F, fs, w.refspec, nullptr, 0, n, w.tw_y, 1, (flags & IAP_REG_NORMALIZE) ? 1 : 0, st);
   if (rc) return rc;
   rc = launch_rows_c2r(p, w.F, fs, n, w.tw_x, w.pval, w.pidx, st);
   if (rc) return rc;
@@ -1308,10 +1326,10 @@ static int reg_estimate_batch(const RegPlan& p, RegWs& w, const uint16_t* mov, l
     const int nch = p.ncg * nuc, nyb = (p.Py + 255) / 256;
     { ProfScope ps_(K_OTHER, st);
       hipLaunchKernelGGL(upsample_tables_kernel, dim3((p.Py + p.Wp + 255) / 256, n), dim3(256), 0, st, p.Py, p.Px, p.Wp,
-                         (const int2*)w.coarse, (const cf*)w.R, fs, w.yrec, w.xrec, w.nyq, nyb); }
+                         (const int2*)w.coarse, (const cf*)w.F, fs, w.yrec, w.xrec, w.nyq, nyb); }
     { ProfScope ps_(K_UPSAMPLE, st);
-      hipLaunchKernelGGL(upsample_partial_kernel, dim3(nch, n), dim3(256), 0, st, (const cf*)w.R, fs, p.Wp, p.Py, p.Px,
-                         p.ncg, ub, (const float*)w.yrec, (const float*)w.xrec, w.upart, nch); }
+      hipLaunchKernelGGL(upsample_partial_kernel, dim3(nch, n), dim3(256), 0, st, (const cf*)w.F, fs, p.Wp, p.Py, p.Px,
+                         p.ncg, ub, (const int2*)w.coarse, (const float*)w.yrec, (const float*)w.xrec, w.upart, nch); }
     { ProfScope ps_(K_UPFINISH, st); hipLaunchKernelGGL(upsample_finish_kernel, dim3(n), dim3(256), 0, st, (const float*)w.upart, nch,
                          (const float*)w.nyq, nyb, (const float*)w.xrec, p.Wp, p.Px,
                        (const int2*)w.coarse, shifts); }
@@ -1525,5 +1543,8 @@ extern "C" int iap_im_reg_u16(const uint16_t* in, uint16_t* out, int64_t T, int 
     rc = reg_estimate_batch(p, w, mp, ms, nb, flags, shifts_out + 2 * f0, st);
     if (rc) return rc;
   }
+  // 'first': frame 0 is the reference itself, its shift is zero by definition (the estimate, summed in f32
+  // from Q, lands within 1e-4 px of it; a non-zero remainder would push the plane's last row or column out)
+  if (ref_mode == IAP_REF_FIRST) IAP_HIP(hipMemsetAsync(shifts_out, 0, 16, st));
   return launch_apply(in, out, T, ppf, Y, X, shifts_out, st);
 }

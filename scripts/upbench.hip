@@ -10,7 +10,8 @@ int main(int argc, char** argv) {
   int nuc = argc > 1 ? atoi(argv[1]) : 12;
   int ub = (((Py + nuc - 1) / nuc) + 3) & ~3; nuc = (Py + ub - 1) / ub;
   size_t fs = (size_t)Py * Wp;
-  cf *R; float *ey, *ex; float* part; long long* st;
+  cf *R; float *ey, *ex; float* part; long long* st; int2* coarse;
+  hipMalloc(&coarse, n * 8); hipMemset(coarse, 0, n * 8);
   hipMalloc(&R, n * fs * 8); hipMemset(R, 0, n * fs * 8);
   hipMalloc(&ey, (size_t)n * Py * 16 * 4); hipMemset(ey, 0, (size_t)n * Py * 16 * 4);
   hipMalloc(&ex, (size_t)n * Wp * 20 * 4); hipMemset(ex, 0, (size_t)n * Wp * 20 * 4);
@@ -23,7 +24,7 @@ int main(int argc, char** argv) {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   for (int k = 0; k < 3; ++k) {
     hipEventRecord(a);
-    hipLaunchKernelGGL(upsample_partial_kernel, dim3(nch, n), dim3(256), 0, 0, R, (long long)fs, Wp, Py, Px, ncg, ub, ey, ex, part, nch);
+    hipLaunchKernelGGL(upsample_partial_kernel, dim3(nch, n), dim3(256), 0, 0, R, (long long)fs, Wp, Py, Px, ncg, ub, (const int2*)coarse, ey, ex, part, nch);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     printf("launch %d: %.1f us total, %.2f us/frame\n", k, ms * 1e3, ms * 1e3 / n);
