@@ -111,6 +111,17 @@ def test_apply_fractional_shifts(dev):
     _check_apply(img, [(0.3, -1.7), (-2.5, 0.25), (0.0, 0.5), (10.2, 0.0), (-0.999, 0.001), (35.5, -64.25)], dev)
 
 
+@pytest.mark.parametrize("nty", [1, 2, 3, 8])
+def test_apply_marching_steps(dev, nty, monkeypatch):
+    """the workgroup's walk down a 64-column strip: several 64-row steps per workgroup (carried x-filtered
+    rows), ragged last step and last strip, walks that start or end outside the image, whole-pixel axes"""
+    monkeypatch.setenv("IAP_APPLY_NTY", str(nty))
+    rng = np.random.default_rng(20 + nty)
+    img = rng.integers(0, 65536, size=(7, 1, 1, 333, 200)).astype(np.uint16)
+    _check_apply(img, [(0.3, -1.7), (-70.5, 0.25), (130.25, -3.0), (-4.0, 66.6), (5.0, -9.0), (-332.5, 0.5),
+                       (400.0, 0.5)], dev)
+
+
 def test_apply_saturation_and_negative_clip(dev):
     """cubic overshoot next to a 0 -> 65535 edge: negatives clip to 0, overshoot saturates"""
     img = np.zeros((1, 1, 64, 64), np.uint16)
