@@ -26,43 +26,54 @@
 
 namespace iap {
 
-typedef float2 cf;
+// complex f32 as a packed pair: the FFT butterflies run on v_pk_add/mul/fma_f32, which issue at the
+// rate of their scalar forms on this part (half the VALU instructions of float2 code)
+typedef float cf __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cf mkc(float x, float y) { return (cf){x, y}; }
 
 // streaming 8-byte load of one complex value (spectra that are read exactly once by a kernel)
-typedef float cf_v2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ cf load_cf_nt(const cf* p) {
-  cf_v2 w = __builtin_nontemporal_load(reinterpret_cast<const cf_v2*>(p));
-  return make_float2(w.x, w.y);
-}
+__device__ __forceinline__ cf load_cf_nt(const cf* p) { return __builtin_nontemporal_load(p); }
 
+// a * b: (a.x b.x, a.x b.y) then + (a.y (-b.y), a.y b.x); the half selects and the sign ride in the
+// second instruction (the compiler materialises such a swizzle with two extra moves)
 __device__ __forceinline__ cf cmul(cf a, cf b) {
-  return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+  const cf t = (cf){a.x, a.x} * b;
+  cf r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+  return r;
 }
-__device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
-// multiply by -i (SIGN < 0, forward) or +i (inverse)
-template <int SIGN>
-__device__ __forceinline__ cf mul_i(cf a) {
-  return SIGN < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
+// c + i d = (c.x - d.y, c.y + d.x) and c - i d = (c.x + d.y, c.y - d.x) as one packed add each
+__device__ __forceinline__ cf addi(cf c, cf d) {
+  cf r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(c), "v"(d));
+  return r;
 }
+__device__ __forceinline__ cf subi(cf c, cf d) {
+  cf r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(c), "v"(d));
+  return r;
+}
+// c + (SIGN i) d: SIGN < 0 is the forward transform
+template <int SIGN> __device__ __forceinline__ cf add_si(cf c, cf d) { return SIGN < 0 ? subi(c, d) : addi(c, d); }
+template <int SIGN> __device__ __forceinline__ cf sub_si(cf c, cf d) { return SIGN < 0 ? addi(c, d) : subi(c, d); }
 
 __device__ __forceinline__ int padi(int i) { return i + (i >> 3); }
 
 template <int SIGN>
 __device__ __forceinline__ void dft2(cf* v) {
-  cf a = v[0], b = v[1];
-  v[0] = cadd(a, b);
-  v[1] = csub(a, b);
+  const cf a = v[0], b = v[1];
+  v[0] = a + b;
+  v[1] = a - b;
 }
 
 template <int SIGN>
 __device__ __forceinline__ void dft4(cf* v) {
-  cf e0 = cadd(v[0], v[2]), e1 = csub(v[0], v[2]);
-  cf o0 = cadd(v[1], v[3]), o1 = mul_i<SIGN>(csub(v[1], v[3]));
-  v[0] = cadd(e0, o0);
-  v[1] = cadd(e1, o1);
-  v[2] = csub(e0, o0);
-  v[3] = csub(e1, o1);
+  const cf e0 = v[0] + v[2], e1 = v[0] - v[2];
+  const cf o0 = v[1] + v[3], d = v[1] - v[3];
+  v[0] = e0 + o0;
+  v[1] = add_si<SIGN>(e1, d);
+  v[2] = e0 - o0;
+  v[3] = sub_si<SIGN>(e1, d);
 }
 
 template <int SIGN>
@@ -71,24 +82,24 @@ __device__ __forceinline__ void dft8(cf* v) {
   cf a[4], b[4];
 #pragma unroll
   for (int n = 0; n < 4; ++n) {
-    a[n] = cadd(v[n], v[n + 4]);
-    b[n] = csub(v[n], v[n + 4]);
-  }
-  // b[n] *= W8^n, W8 = exp(SIGN * 2 pi i / 8)
-  {
-    cf t = b[1];  // (1 + SIGN i)/sqrt2
-    b[1] = SIGN < 0 ? make_float2(h * (t.x + t.y), h * (t.y - t.x)) : make_float2(h * (t.x - t.y), h * (t.y + t.x));
-    b[2] = mul_i<SIGN>(b[2]);
-    t = b[3];  // (-1 + SIGN i)/sqrt2
-    b[3] = SIGN < 0 ? make_float2(h * (t.y - t.x), -h * (t.x + t.y)) : make_float2(-h * (t.x + t.y), h * (t.x - t.y));
+    a[n] = v[n] + v[n + 4];
+    b[n] = v[n] - v[n + 4];
   }
   dft4<SIGN>(a);
-  dft4<SIGN>(b);
-#pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    v[2 * m] = a[m];
-    v[2 * m + 1] = b[m];
-  }
+  // b[n] *= W8^n, W8 = exp(SIGN 2 pi i / 8), folded into the 4-point transform of b:
+  //   b1' = h (b1 + SIGN i b1),  b2' = SIGN i b2,  b3' = -h (b3 - SIGN i b3)
+  const cf b1 = add_si<SIGN>(b[1], b[1]) * (cf){h, h};
+  const cf x3 = sub_si<SIGN>(b[3], b[3]);
+  const cf e0 = add_si<SIGN>(b[0], b[2]), e1 = sub_si<SIGN>(b[0], b[2]);
+  const cf o0 = __builtin_elementwise_fma(x3, (cf){-h, -h}, b1), d = __builtin_elementwise_fma(x3, (cf){h, h}, b1);
+  v[0] = a[0];
+  v[1] = e0 + o0;
+  v[2] = a[1];
+  v[3] = add_si<SIGN>(e1, d);
+  v[4] = a[2];
+  v[5] = e0 - o0;
+  v[6] = a[3];
+  v[7] = sub_si<SIGN>(e1, d);
 }
 
 template <int R, int SIGN>
@@ -168,7 +179,7 @@ __global__ void twiddle_kernel(cf* tw, int n) {
   if (k < n) {
     double s, c;
     sincospi(-2.0 * (double)k / (double)n, &s, &c);
-    tw[k] = make_float2((float)c, (float)s);
+    tw[k] = mkc((float)c, (float)s);
   }
 }
 
@@ -196,12 +207,12 @@ __global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_r2c_kernel
     const uint16_t* p16 = reinterpret_cast<const uint16_t*>(src);
     u16x8 qa = load8(p16 + offa + 8 * j), qb = load8(p16 + offb + 8 * j);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s[padi(8 * j + k)] = make_float2((float)qa.v[k] * in_scale, (float)qb.v[k] * in_scale);
+    for (int k = 0; k < 8; ++k) s[padi(8 * j + k)] = mkc((float)qa.v[k] * in_scale, (float)qb.v[k] * in_scale);
   } else {
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       int n = j + m * Gm::NT;
-      s[padi(n)] = make_float2(load_src(src, kind, offa + n) * in_scale, load_src(src, kind, offb + n) * in_scale);
+      s[padi(n)] = mkc(load_src(src, kind, offa + n) * in_scale, load_src(src, kind, offb + n) * in_scale);
     }
   }
   __syncthreads();
@@ -211,8 +222,8 @@ __global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_r2c_kernel
   for (int k = j; k <= N / 2; k += Gm::NT) {
     cf zk = s[padi(k)];
     cf zn = s[padi((N - k) & (N - 1))];
-    Fa[k] = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-    Fb[k] = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+    Fa[k] = mkc(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+    Fb[k] = mkc(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
   }
 }
 
@@ -245,8 +256,8 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_kerne
     const int idx = tid + m * NTH;               // pair index: (row u, pair pc)
     const int pc = idx % HP, u = idx / HP;
     const float4 w = *reinterpret_cast<const float4*>(Ff + (size_t)u * Wp + v0 + 2 * pc);
-    lds_c[(2 * pc) * Gm::CS + padi(u)] = make_float2(w.x, w.y);
-    lds_c[(2 * pc + 1) * Gm::CS + padi(u)] = make_float2(w.z, w.w);
+    lds_c[(2 * pc) * Gm::CS + padi(u)] = mkc(w.x, w.y);
+    lds_c[(2 * pc + 1) * Gm::CS + padi(u)] = mkc(w.z, w.w);
   }
   __syncthreads();
   fft_lds<N, -1, Gm::CE>(s, j, tw);
@@ -259,15 +270,15 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_kerne
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const cf g = lds_c[(2 * pc + h) * Gm::CS + padi(u)];
-        const cf f = h ? make_float2(f2.z, f2.w) : make_float2(f2.x, f2.y);
-        cf p = make_float2((f.x * g.x + f.y * g.y) * scale, (f.y * g.x - f.x * g.y) * scale);
+        const cf f = h ? mkc(f2.z, f2.w) : mkc(f2.x, f2.y);
+        cf p = mkc((f.x * g.x + f.y * g.y) * scale, (f.y * g.x - f.x * g.y) * scale);
         if (normalize) {
           float m2 = p.x * p.x + p.y * p.y;
           float inv = m2 > 0.f ? rsqrtf(m2) : 0.f;
           p.x *= inv;
           p.y *= inv;
         }
-        if (u == 0 && v0 + 2 * pc + h == 0) p = make_float2(0.f, 0.f);
+        if (u == 0 && v0 + 2 * pc + h == 0) p = mkc(0.f, 0.f);
         lds_c[(2 * pc + h) * Gm::CS + padi(u)] = p;
       }
     }
@@ -339,8 +350,8 @@ __global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_c2r_argmax
       a.y = 0.f;
       b.y = 0.f;
     }
-    s[padi(k)] = make_float2(a.x - b.y, a.y + b.x);
-    if (k > 0 && k < N / 2) s[padi(N - k)] = make_float2(a.x + b.y, b.x - a.y);
+    s[padi(k)] = mkc(a.x - b.y, a.y + b.x);
+    if (k > 0 && k < N / 2) s[padi(N - k)] = mkc(a.x + b.y, b.x - a.y);
   }
   __syncthreads();
   fft_lds<N, +1>(s, j, tw);
@@ -405,7 +416,7 @@ constexpr int UP_YS = 16;      // floats per row record   {Ks(y'_0 - y) .. Ks(y'
 constexpr int UP_XS = 20;      // floats per column record {w base.x, w base.y, 0, 0 | 1, a1..a7 | b1..b7, 0}
 constexpr int UP_NV = UP_N * UP_N;  // 225 grid values
 constexpr int UP_NQ = 32;      // floats per Nyquist-column partial: the 16 weighted row sums as complex pairs
-typedef float v2f __attribute__((ext_vector_type(2)));
+typedef cf v2f;
 
 __device__ __forceinline__ cf unit_phase(int freq, int ishift, int n, float frac_shift) {
   // exp(2 pi i * freq * (ishift + frac_shift) / n); the integer part is reduced exactly
@@ -413,7 +424,7 @@ __device__ __forceinline__ cf unit_phase(int freq, int ishift, int n, float frac
   float rev = (float)a / (float)n + (float)freq * frac_shift / (float)n;
   float sn, cs;
   sincospif(2.0f * rev, &sn, &cs);
-  return make_float2(cs, sn);
+  return mkc(cs, sn);
 }
 
 #ifdef IAP_UP_STAMPS
