@@ -41,6 +41,7 @@ SIGNATURES = {
     "iap_label_mode_u16": (_i32, [_vp, _i32, _i64, _vp, _vp, _vp]),
     "iap_label_erode_u16": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     "iap_label_dilate_u16": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "iap_label_sub_u16": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "iap_tiff_probe": (_i32, [C.c_char_p] + [C.POINTER(_i32)] * 6),
     "iap_tiff_read_u16": (_i32, [C.POINTER(C.c_char_p), _i64, _vp, _i32, _i32, _i32]),
     "iap_tiff_write_u16": (_i32, [C.POINTER(C.c_char_p), _i64, _vp, _i32, _i32, _i32]),

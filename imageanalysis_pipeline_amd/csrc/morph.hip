@@ -8,6 +8,7 @@
 // label image: the largest label inside the disk (border -inf).  disk(r) is skimage's: dx^2 + dy^2 <= r^2.
 // One workgroup computes a 32 x 32 tile from an LDS copy with an r-pixel halo; every thread walks
 // the row spans of the disk (exact, integer).
+#include <algorithm>
 #include "common.h"
 
 namespace iap {
@@ -95,9 +96,39 @@ static int launch_morph(const uint16_t* in, uint16_t* out, int64_t n, int Y, int
   return IAP_OK;
 }
 
+// out = a - b on u16 label planes (membrane = full mask - eroded mask, experiments.py:259), 8 px per lane
+__global__ __launch_bounds__(256) void label_sub_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
+                                                        uint16_t* __restrict__ out, long long n) {
+  const long long nv = n >> 3;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
+    const u16x8 va = load8(a + i * 8), vb = load8(b + i * 8);
+    u16x8 vo;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) vo.v[k] = (uint16_t)(va.v[k] - vb.v[k]);
+    store8(out + i * 8, vo);
+  }
+  if (blockIdx.x == 0) {
+    const long long t = nv * 8 + threadIdx.x;
+    if (t < n) out[t] = (uint16_t)(a[t] - b[t]);
+  }
+}
+
 }  // namespace iap
 
 using namespace iap;
+
+extern "C" int iap_label_sub_u16(const uint16_t* a, const uint16_t* b, uint16_t* out, int64_t n, void* stream) {
+  IAP_REQUIRE(a && b && out, IAP_E_ARG, "iap_label_sub_u16: null pointer");
+  IAP_REQUIRE(n > 0, IAP_E_ARG, "iap_label_sub_u16: non-positive size");
+  IAP_REQUIRE(aligned16(a) && aligned16(b) && aligned16(out), IAP_E_ALIGN, "iap_label_sub_u16: buffers must be 16-byte aligned");
+  hipStream_t st = as_stream(stream);
+  unsigned g = (unsigned)std::min<int64_t>((n / 8 + 255) / 256, 4096);
+  if (g == 0) g = 1;
+  { ProfScope ps_(K_OTHER, st);
+    hipLaunchKernelGGL(label_sub_kernel, dim3(g), dim3(256), 0, st, a, b, out, (long long)n); }
+  IAP_LAUNCH_CHECK();
+  return IAP_OK;
+}
 
 extern "C" int iap_label_erode_u16(const uint16_t* in, uint16_t* out, int64_t n, int Y, int X, int radius, int iterations,
                                    void* ws, size_t ws_bytes, void* stream) {

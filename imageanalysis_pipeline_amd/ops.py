@@ -456,3 +456,32 @@ def label_erode(masks: torch.Tensor, radius: int, iterations: int = 1) -> torch.
 def label_dilate(masks: torch.Tensor, radius: int, iterations: int = 1) -> torch.Tensor:
     """utility.py:804-826 on u16 label planes (..., Y, X): grey dilation (largest label) with disk(radius)."""
     return _label_morph("iap_label_dilate_u16", masks, radius, iterations)
+
+
+def label_sub(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """experiments.py:259: a - b element-wise on u16 label stacks of one shape (membrane = full - eroded)."""
+    _need_cuda(a, b)
+    _u16(a)
+    _u16(b)
+    if a.shape != b.shape:
+        raise ValueError("label_sub: shapes differ")
+    a, b = a.contiguous(), b.contiguous()
+    if out is None:
+        out = torch.empty_like(a)
+    _lib.check(_lib.load().iap_label_sub_u16(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()),
+               "iap_label_sub_u16")
+    return out
+
+
+def label_areas(masks: torch.Tensor, n_labels: int | None = None) -> torch.Tensor:
+    """Pixel count per (frame, label) of a u16 label stack (T, [Z,] Y, X) -> int64 (T, L)
+    (experiments.py:200-201: ``np.unique(t, return_counts=True)`` of one object at a time).  The label
+    stack doubles as the one-channel image of the measuring kernel; only its counts are kept."""
+    _need_cuda(masks)
+    _u16(masks)
+    if masks.dim() == 3:
+        masks = masks[:, None]
+    if masks.dim() != 4:
+        raise ValueError("label_areas: masks must be (T, Y, X) or (T, Z, Y, X)")
+    masks = masks.contiguous()
+    return measure_accumulate(masks[:, None], masks, n_labels)[..., 0].contiguous()

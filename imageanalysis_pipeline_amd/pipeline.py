@@ -333,7 +333,56 @@ class Utility:
         Utility._stitch_pass(d, lambda i: master, thr, new_ids=False)
         return ops.to_numpy_u16(d).astype(np.asarray(masks).dtype)
 
+    # ------------------------------------------------------------------ track clean-up (experiments.py:195-221)
+    @staticmethod
+    def filter_mask_shapes(masks, shape_threshold=0.2):
+        """experiments.py:195-206: an object is removed from the frames where its area is more than
+        shape_threshold away (relative) from its mean area over the frames that hold it."""
+        d = ops.to_device_u16(np.ascontiguousarray(masks).astype(np.uint16), _device())
+        area = ops.label_areas(d).cpu().numpy().astype(np.float64)            # (T, L)
+        present = area > 0
+        with np.errstate(invalid="ignore", divide="ignore"):
+            mean = area.sum(axis=0) / present.sum(axis=0)
+        up, down = mean + mean * shape_threshold, mean - mean * shape_threshold
+        drop = present & ((area < down) | (area > up))
+        drop[:, 0] = False
+        lut = np.broadcast_to(np.arange(area.shape[1], dtype=np.uint16), area.shape).copy()
+        lut[drop] = 0
+        out = ops.relabel(d, ops.to_device_u16(lut, d.device))
+        return ops.to_numpy_u16(out).astype(np.float64)      # the reference accumulates into np.zeros(shape)
+
+    @staticmethod
+    def renumber_masks(masks):
+        """experiments.py:208-211: labels replaced by their rank among the values present."""
+        d = ops.to_device_u16(np.ascontiguousarray(masks).astype(np.uint16), _device())
+        present = ops.label_areas(d).sum(dim=0).cpu().numpy() > 0
+        lut = (np.cumsum(present) - 1).clip(min=0).astype(np.uint16)
+        out = ops.relabel(d, ops.to_device_u16(lut, d.device))
+        return ops.to_numpy_u16(out).astype(np.asarray(masks).dtype)
+
+    @staticmethod
+    def trim_incomplete_tracks(masks, frames=None):
+        """experiments.py:217-221: objects that are not present in every frame are removed."""
+        d = ops.to_device_u16(np.ascontiguousarray(masks).astype(np.uint16), _device())
+        n_frames = np.asarray(masks).shape[0] if frames is None else int(frames)
+        present = (ops.label_areas(d) > 0).sum(dim=0).cpu().numpy()
+        lut = np.arange(present.shape[0], dtype=np.uint16)
+        lut[(present != n_frames)] = 0
+        out = ops.relabel(d, ops.to_device_u16(lut, d.device))
+        return ops.to_numpy_u16(out).astype(np.asarray(masks).dtype)
+
     # ------------------------------------------------------------------ compartments (utility.py:776-826)
+    @staticmethod
+    def compartment_masks(mask_stack, exp_para, rad_ero=10, rad_dil=None, dil_iteration=1, ero_iteration=1):
+        """experiments.py:251-262 (Exp_Indiv.cell_compart, the mask arithmetic): optional dilation, erosion,
+        membrane = full - eroded.  Returns (mask_mb, mask_cyto, mask_full) as the reference saves them."""
+        d = ops.to_device_u16(np.ascontiguousarray(mask_stack).astype(np.uint16), _device())
+        if rad_dil:
+            d = ops.label_dilate(d, int(rad_dil), int(dil_iteration))
+        ero = ops.label_erode(d, int(rad_ero), int(ero_iteration))
+        mb = ops.label_sub(d, ero)
+        return ops.to_numpy_u16(mb), ops.to_numpy_u16(ero), ops.to_numpy_u16(d)
+
     @staticmethod
     def erode_mask(mask_stack, exp_para, rad_ero, **kwargs):
         """utility.py:776-801: per-object cv2.erode with disk(rad_ero), summed; kwargs: iterations."""

@@ -187,6 +187,10 @@ int iap_label_erode_u16(const uint16_t* in, uint16_t* out, int64_t n, int Y, int
 int iap_label_dilate_u16(const uint16_t* in, uint16_t* out, int64_t n, int Y, int X, int radius, int iterations,
                          void* ws, size_t ws_bytes, void* stream);
 
+/* Exp_Indiv.cell_compart (experiments.py:259): mask_mb = mask_stack - mask_erode, element-wise on n u16
+ * values (the eroded mask is a subset of the full one with the same labels, so no value wraps). */
+int iap_label_sub_u16(const uint16_t* a, const uint16_t* b, uint16_t* out, int64_t n, void* stream);
+
 /* ------------------------------------------------------------------ plane files (host) -- */
 
 /* The step on either side of the hot path: the reference keeps every

@@ -648,3 +648,48 @@ def label_dilate(mask: np.ndarray, r: int, iterations: int = 1) -> np.ndarray:
             out[yd, xd] = np.maximum(out[yd, xd], m[ys, xs])
         m = out
     return m
+
+
+# ---------------------------------------------------------------------------------------------
+# Track clean-up after stitching (experiments.py:195-221) and compartments (experiments.py:251-262)
+
+def filter_mask_shapes(masks: np.ndarray, shape_threshold: float = 0.2) -> np.ndarray:
+    """experiments.py:195-206, the reference's loop as written (one object at a time)."""
+    new_mask = np.zeros(masks.shape)
+    for obj in list(np.unique(masks))[1:]:
+        temp = masks.copy()
+        temp[temp != obj] = 0
+        t = np.where(temp != 0)[0]
+        f_lst, size_lst = np.unique(t, return_counts=True)
+        mean_size = np.mean(size_lst)
+        up = mean_size + mean_size * shape_threshold
+        down = mean_size - mean_size * shape_threshold
+        temp[f_lst[np.where((size_lst < down) | (size_lst > up))]] = 0
+        new_mask += temp
+    return new_mask
+
+
+def renumber_masks(masks: np.ndarray) -> np.ndarray:
+    """experiments.py:208-211."""
+    out = masks.copy()
+    for n, val in enumerate(list(np.unique(out))):
+        out[out == val] = n
+    return out
+
+
+def trim_incomplete_tracks(masks: np.ndarray, frames: int) -> np.ndarray:
+    """experiments.py:217-221."""
+    out = masks.copy()
+    for obj in list(np.unique(out))[1:]:
+        if len(set(np.where(out == obj)[0])) != frames:
+            out[out == obj] = 0
+    return out
+
+
+def compartment_masks(mask_stack: np.ndarray, rad_ero: int, rad_dil=None, dil_iteration=1, ero_iteration=1):
+    """experiments.py:251-262 with this module's label_erode / label_dilate: (mb, cyto, full)."""
+    full = mask_stack
+    if rad_dil:
+        full = np.stack([label_dilate(p, rad_dil, dil_iteration) for p in full.reshape(-1, *full.shape[-2:])]).reshape(full.shape)
+    ero = np.stack([label_erode(p, rad_ero, ero_iteration) for p in full.reshape(-1, *full.shape[-2:])]).reshape(full.shape)
+    return full - ero, ero, full

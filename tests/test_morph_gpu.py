@@ -61,3 +61,20 @@ def test_shim_erode_dilate_and_errors(dev):
     assert single.shape == lab.shape and np.array_equal(single, O.label_erode(lab, 3))
     with pytest.raises(ValueError):
         ops.label_erode(ops.to_device_u16(lab, dev), 40)
+
+
+def test_compartment_masks(dev):
+    """experiments.py:251-262: dilate, erode, membrane = full - eroded, against the oracle's composition"""
+    from imageanalysis_pipeline_amd.pipeline import Utility
+    rng = np.random.default_rng(4)
+    m = np.zeros((2, 80, 90), np.uint16)
+    yy, xx = np.mgrid[:80, :90]
+    for lab in range(1, 9):
+        cy, cx = rng.integers(8, 72), rng.integers(8, 82)
+        for f in range(2):
+            m[f][(yy - cy) ** 2 + (xx - cx) ** 2 <= 64] = lab
+    for kw in (dict(rad_ero=3), dict(rad_ero=2, rad_dil=2, ero_iteration=2)):
+        mb, cyto, full = Utility.compartment_masks(m, {"t": 2, "z": 1}, **kw)
+        emb, ecyto, efull = O.compartment_masks(m, kw["rad_ero"], kw.get("rad_dil"), 1, kw.get("ero_iteration", 1))
+        assert np.array_equal(full, efull) and np.array_equal(cyto, ecyto) and np.array_equal(mb, emb)
+        assert np.array_equal(mb.astype(np.int64) + cyto, full)

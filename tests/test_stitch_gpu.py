@@ -78,3 +78,45 @@ def test_modif_stitch3D_matches_oracle(dev):
     empty_first = st.copy()
     empty_first[0] = 0                                                    # the 'empty' branches of the loop
     assert np.array_equal(Utility.modif_stitch3D(empty_first, 0.75), O.modif_stitch3D(empty_first, 0.75))
+
+
+def _tracks(seed=3, t=6, y=96, x=128):
+    """discs that persist over time, some with an outlier area in one frame, some missing in frames"""
+    rng = np.random.default_rng(seed)
+    m = np.zeros((t, y, x), np.uint16)
+    yy, xx = np.mgrid[:y, :x]
+    for lab in range(1, 13):
+        cy, cx = rng.integers(10, y - 10), rng.integers(10, x - 10)
+        for f in range(t):
+            if lab % 4 == 0 and f == lab % t:
+                continue                                   # gap: an incomplete track
+            r = 5 + (4 if (lab % 3 == 0 and f == 2) else 0)  # one swollen frame
+            m[f][(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = lab * 3   # non-consecutive ids
+    return m
+
+
+def test_filter_mask_shapes_matches_reference_loop(dev):
+    from imageanalysis_pipeline_amd.pipeline import Utility
+    m = _tracks()
+    got = Utility.filter_mask_shapes(m, shape_threshold=0.2)
+    exp = O.filter_mask_shapes(m, 0.2)
+    assert got.dtype == exp.dtype and np.array_equal(got, exp)
+    assert (got != m).any()                                 # the swollen frames were dropped
+
+
+def test_renumber_and_trim_match_reference_loops(dev):
+    from imageanalysis_pipeline_amd.pipeline import Utility
+    m = _tracks(seed=5)
+    assert np.array_equal(Utility.renumber_masks(m), O.renumber_masks(m))
+    assert np.array_equal(Utility.trim_incomplete_tracks(m), O.trim_incomplete_tracks(m, m.shape[0]))
+    nob = m.copy()
+    nob[nob == 0] = 7                                       # no background: rank 0 goes to the smallest label
+    assert np.array_equal(Utility.renumber_masks(nob), O.renumber_masks(nob))
+
+
+def test_label_areas_are_bincounts(dev):
+    from imageanalysis_pipeline_amd import ops
+    m = _tracks(seed=8)
+    a = ops.label_areas(ops.to_device_u16(m, dev)).cpu().numpy()
+    for f in range(m.shape[0]):
+        assert np.array_equal(a[f], np.bincount(m[f].ravel(), minlength=a.shape[1]))
