@@ -762,9 +762,38 @@ __global__ __launch_bounds__(256) void mip_kernel(const uint16_t* __restrict__ i
   }
 }
 
-// sum[i] += sum over n planes (stride apart) of plane[i]
+// sum[i] += sum over n planes (stride apart) of plane[i]; vec: 8 pixels per lane as 16-byte loads, four
+// planes in flight
 __global__ __launch_bounds__(256) void accum_planes_kernel(const uint16_t* __restrict__ in, long long stride,
-                                                           long long n, long long px, uint32_t* __restrict__ sum) {
+                                                           long long n, long long px, uint32_t* __restrict__ sum,
+                                                           int vec) {
+  if (vec) {
+    const long long nv = px >> 3;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv;
+         i += (long long)gridDim.x * blockDim.x) {
+      uint32_t s[8];
+      const uint4 s0 = reinterpret_cast<const uint4*>(sum)[2 * i], s1 = reinterpret_cast<const uint4*>(sum)[2 * i + 1];
+      s[0] = s0.x; s[1] = s0.y; s[2] = s0.z; s[3] = s0.w; s[4] = s1.x; s[5] = s1.y; s[6] = s1.z; s[7] = s1.w;
+      long long k = 0;
+      for (; k + 4 <= n; k += 4) {
+        u16x8 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = load8_nt(in + (k + q) * stride + i * 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s[e] += v[q].v[e];
+      }
+      for (; k < n; ++k) {
+        const u16x8 v = load8_nt(in + k * stride + i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += v.v[e];
+      }
+      reinterpret_cast<uint4*>(sum)[2 * i] = make_uint4(s[0], s[1], s[2], s[3]);
+      reinterpret_cast<uint4*>(sum)[2 * i + 1] = make_uint4(s[4], s[5], s[6], s[7]);
+    }
+    return;
+  }
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < px;
        i += (long long)gridDim.x * blockDim.x) {
     uint32_t s = sum[i];
@@ -1541,7 +1570,8 @@ extern "C" int iap_im_reg_u16(const uint16_t* in, uint16_t* out, int64_t T, int 
       long long ms;
       rc = mov_planes(in, f0, nb, mp, ms);
       if (rc) return rc;
-      { ProfScope ps_(K_ACCUM, st); hipLaunchKernelGGL(accum_planes_kernel, dim3(gx), dim3(256), 0, st, mp, ms, (long long)nb, px, w.sum); }
+      const int vec = px % 8 == 0 && ms % 8 == 0 && aligned16(mp) && aligned16(w.sum);
+      { ProfScope ps_(K_ACCUM, st); hipLaunchKernelGGL(accum_planes_kernel, dim3(vec ? (unsigned)std::min<long long>((px / 8 + 255) / 256, 4096) : gx), dim3(256), 0, st, mp, ms, (long long)nb, px, w.sum, vec); }
     }
     IAP_LAUNCH_CHECK();
     rc = reg_ref_spectrum(p, w, w.sum, 1, 1.0f / (float)T, st);
