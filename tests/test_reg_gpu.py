@@ -122,6 +122,14 @@ def test_apply_marching_steps(dev, nty, monkeypatch):
                        (400.0, 0.5)], dev)
 
 
+@pytest.mark.parametrize("shape", [(8, 6), (33, 17), (5, 70), (64, 64), (65, 129)])
+def test_apply_small_and_ragged_planes(dev, shape):
+    """planes smaller than a strip or a step, narrower than one 16-byte load (X < 8), one pixel over a multiple"""
+    rng = np.random.default_rng(shape[0] * 131 + shape[1])
+    img = rng.integers(0, 65536, size=(4, 2) + shape).astype(np.uint16)
+    _check_apply(img, [(0.4, -0.2), (-1.0, 0.75), (2.5, 3.0), (0.0, 0.0)], dev)
+
+
 def test_apply_saturation_and_negative_clip(dev):
     """cubic overshoot next to a 0 -> 65535 edge: negatives clip to 0, overshoot saturates"""
     img = np.zeros((1, 1, 64, 64), np.uint16)
