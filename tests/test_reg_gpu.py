@@ -26,7 +26,7 @@ def test_mip(dev):
     assert np.array_equal(got, a.max(axis=1))
 
 
-@pytest.mark.parametrize("shape", [(64, 64), (128, 256), (256, 128), (512, 512), (100, 300), (1024, 64)])
+@pytest.mark.parametrize("shape", [(64, 64), (128, 256), (256, 128), (512, 512), (100, 300), (1024, 64), (4096, 64), (64, 4096)])
 def test_integer_shifts_exact(dev, shape):
     """integer-shifted frames: coarse estimate equals the oracle's (and the injected drift)"""
     from imageanalysis_pipeline_amd import ops
@@ -44,7 +44,7 @@ def fft_is_full(shape):
     return all(O.fft_window(n) == n for n in shape)
 
 
-@pytest.mark.parametrize("shape", [(256, 256), (128, 512), (200, 260)])
+@pytest.mark.parametrize("shape", [(256, 256), (128, 512), (200, 260), (4096, 128)])
 def test_subpixel_shifts_within_tolerance(dev, shape):
     from imageanalysis_pipeline_amd import ops
     y, x = shape
