@@ -1401,7 +1401,7 @@ static int launch_apply(const uint16_t* in, uint16_t* out, long long n_frames, l
   const char* e = getenv("IAP_APPLY_NTY");   // experiments and tests: taken as given
   if (e && atoi(e) > 0) nty = atoi(e);
   else
-    while (nty > 1 && (long long)tiles_x * ((tiles_y + nty - 1) / nty) * ppf * n_frames < 8192) nty >>= 1;
+    while (nty > 1 && (long long)tiles_x * ((tiles_y + nty - 1) / nty) * ppf * n_frames < 2048) nty >>= 1;
   dim3 grid(tiles_x, (tiles_y + nty - 1) / nty, 1);
   // blockIdx.z is limited to 65535: chunk by whole frames
   long long fpc = 65535 / ppf;
