@@ -6,6 +6,11 @@ DataFrames (core.py:336).
 
 Row layout (float64 matrix, exact for every field: ids/areas < 2**53):
     fov, frame, label, area, mean[0..C-1], centroid z, y, x
+
+A single large FOV can instead be split into time blocks (``process_fov_timeblocks``): background
+subtraction, warping and measuring are per frame, and with ``reg_ref`` 'first' or 'mean' every frame is
+registered against one plane, which is the path's only exchange: a broadcast of frame 0's plane (8 MB at
+2048^2) or an all-reduce of the plane sums (16 MB).  'previous' is serial in time and does not shard.
 """
 from __future__ import annotations
 
@@ -81,3 +86,72 @@ def process_plate(load_fov, n_fov: int, threshold: float, reg_ref: str = "mean",
     if rows is None:
         rows = torch.zeros((0, int(width.item())), dtype=torch.float64, device=width.device)
     return gather_rows(rows, group)
+
+
+def shard_frames(n_frames: int, rank: int, world: int) -> range:
+    """Contiguous time blocks, as shard_fovs."""
+    return shard_fovs(n_frames, rank, world)
+
+
+def reference_plane(planes: torch.Tensor, t0: int, n_frames: int, reg_ref: str, group=None) -> torch.Tensor:
+    """The plane every frame is registered against (utility.py:332-366), from this rank's (MIP) planes
+    u16 (tb, Y, X) of the registration channel, frames t0 .. t0+tb-1 of n_frames.
+    'first': frame 0's plane, broadcast by the rank that holds it -> u16 (Y, X).
+    'mean':  sum over all frames (exact int32 sums, all-reduced) times float32(1/n_frames) -> f32 (Y, X),
+             the very values iap_im_reg_u16 feeds its reference spectrum (sum as f32, scaled on load)."""
+    if reg_ref not in ("first", "mean"):
+        raise ValueError(f"time blocks cannot shard reg_ref={reg_ref!r} ('previous' is serial in time)")
+    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    host = multi and dist.get_backend(group) == "gloo"      # gloo moves host tensors (tests, rehearsals)
+    dev = planes.device
+    if reg_ref == "first":
+        if not multi:
+            return planes[0].clone()
+        has0 = t0 == 0 and planes.shape[0] > 0
+        buf = (planes[0].clone() if has0 else torch.zeros(planes.shape[1:], dtype=torch.uint16, device=dev)).view(torch.uint8)   # as bytes: a type every backend moves
+        if host:
+            buf = buf.cpu()
+        # the rank holding frame 0: rank 0 under the block distribution whenever it holds a frame at all
+        src = torch.tensor([dist.get_rank(group) if has0 else -1], dtype=torch.int64, device=buf.device)
+        dist.all_reduce(src, op=dist.ReduceOp.MAX, group=group)
+        dist.broadcast(buf, src=dist.get_global_rank(group, int(src.item())) if group is not None else int(src.item()),
+                       group=group)
+        return buf.to(dev).view(torch.uint16)
+    total = planes.to(torch.int32).sum(dim=0, dtype=torch.int32) if planes.shape[0] else \
+        torch.zeros(planes.shape[1:], dtype=torch.int32, device=dev)
+    if multi:
+        if host:
+            total = total.cpu()
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+        total = total.to(dev)
+    return total.to(torch.float32) * torch.tensor(1.0 / n_frames, dtype=torch.float32, device=dev)
+
+
+def process_fov_timeblocks(load_block, n_frames: int, threshold: float, reg_ref: str = "first", reg_channel: int = 0,
+                           fov: int = 0, group=None):
+    """One FOV split into contiguous time blocks, one per rank: bg_smo -> reference exchange -> estimate ->
+    apply -> measure on the block, rows gathered with global frame numbers.  ``load_block(t0, t1)`` returns
+    (stack u16 (t1-t0, C, Z, Y, X), labels u16 (t1-t0, Z, Y, X)) as device tensors.  Every rank returns
+    (rows of all frames, this block's shifts f64 (t1-t0, 2)); the arithmetic per frame is that of
+    ops.im_reg, so the rows equal a single-process run."""
+    from . import ops
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    frames = shard_frames(n_frames, rank, world)
+    t0, t1 = frames.start, frames.stop
+    stack, labels = load_block(t0, t1)
+    bg, _, _ = ops.bg_smo(stack, threshold, out=stack)
+    tb, c, z, y, x = bg.shape
+    ch = bg[:, reg_channel]                                          # (tb, Z, Y, X)
+    planes = ops.mip(ch.contiguous()) if z > 1 else ch[:, 0].contiguous()
+    ref = reference_plane(planes, t0, n_frames, reg_ref, group)
+    shifts = ops.estimate_shifts(ref, planes) if tb else torch.zeros((0, 2), dtype=torch.float64, device=bg.device)
+    if reg_ref == "first" and t0 == 0 and tb:
+        shifts[0] = 0.0                                              # frame 0 is the reference itself (as ops.im_reg)
+    reg = ops.apply_shifts(bg, shifts) if tb else bg
+    if tb:
+        rows = pack_rows(ops.measure_finalize(ops.measure_accumulate(reg, labels)), fov)
+        rows[:, 1] += float(t0)
+    else:
+        rows = torch.zeros((0, 4 + c + 3), dtype=torch.float64, device=bg.device)
+    return gather_rows(rows, group), shifts

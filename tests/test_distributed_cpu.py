@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from imageanalysis_pipeline_amd.distributed import gather_rows, pack_rows, shard_fovs
+from imageanalysis_pipeline_amd.distributed import gather_rows, pack_rows, reference_plane, shard_fovs, shard_frames
 
 
 def test_shard_fovs_partitions_exactly():
@@ -78,3 +78,46 @@ def test_gather_rows_world2_gloo():
     for rank, rows, n_empty in res:
         assert np.array_equal(rows, exp)                    # rank order == FOV order, identical on every rank
         assert n_empty == sum(3 + f for f in shard_fovs(5, 0, 2))
+
+
+def _ref_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(3)
+        t = 5
+        planes = torch.from_numpy(rng.integers(0, 65536, size=(t, 6, 8)).astype(np.int32)).to(torch.uint16)
+        fr = shard_frames(t, rank, world)
+        mine = planes[fr.start:fr.stop]
+        first = reference_plane(mine, fr.start, t, "first")
+        mean = reference_plane(mine, fr.start, t, "mean")
+        q.put((rank, first.view(torch.int16).numpy(), mean.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reference_plane_exchange_two_ranks():
+    """time-block sharding: every rank ends up with frame 0's plane ('first') and with the scaled exact sum
+    of all planes ('mean'), bit for bit what one process computes"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ref_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    rng = np.random.default_rng(3)
+    planes = rng.integers(0, 65536, size=(5, 6, 8)).astype(np.int32)
+    exp_mean = planes.sum(0).astype(np.float32) * np.float32(1.0 / 5)
+    for _, first, mean in got:
+        assert np.array_equal(first.view(np.uint16), planes[0].astype(np.uint16))
+        assert np.array_equal(mean, exp_mean)
+    one = reference_plane(torch.from_numpy(planes).to(torch.uint16), 0, 5, "mean")
+    assert np.array_equal(one.numpy(), exp_mean)
+    try:
+        reference_plane(torch.zeros((1, 2, 2), dtype=torch.uint16), 0, 1, "previous")
+        assert False
+    except ValueError:
+        pass
