@@ -675,10 +675,11 @@ static SmoGeom smo_geom(int Y, int X, int band) {
 
 static int pick_band(int Y, int64_t n) {
   if (const char* e = getenv("IAP_SMO_BAND")) { int b = atoi(e); if (b >= 8) return b; }
-  // enough waves to fill 256 CUs x 16 waves while keeping the 6-row priming overhead small
-  // 64 rows: 9 % priming overhead; only ~2048 waves are resident (2 per SIMD), so ~3000 suffice
-  int band = 64;
-  while (band > 16 && n * ((Y + band - 1) / band) * 9 < 3000) band >>= 1;
+  // every band re-primes its 7-row ring (6 rows: 4.7 % at 128 rows, 9 % at 64); ~3072 waves are resident
+  // (3 per SIMD), so bands shrink only while fewer than ~4 rounds of waves would be in flight.
+  // Measured on C2 (128 planes a launch): 64 rows 14.85, 128 rows 14.26, 256 rows 14.26, 512 rows 15.4 ms/step
+  int band = 128;
+  while (band > 16 && n * ((Y + band - 1) / band) * 9 < 12000) band >>= 1;
   return band;
 }
 
