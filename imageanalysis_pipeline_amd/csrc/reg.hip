@@ -344,15 +344,23 @@ __global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_c2r_argmax
   const int ra = 2 * pair, rb = ra + 1;
   const cf* Qa = Q + (size_t)blockIdx.y * Q_stride + (size_t)ra * Wp;
   const cf* Qb = Qa + Wp;
-  for (int k = j; k <= N / 2; k += Gm::NT) {
-    cf a = load_cf_nt(Qa + k), b = load_cf_nt(Qb + k);
+  // two neighbouring bins per lane and row as one 16-byte streaming load; the Nyquist bin on its own
+  auto put = [&](int k, cf a, cf b) {
     if (k == 0 || k == N / 2) {  // c2r convention: the imaginary parts of the self-conjugate bins are ignored
       a.y = 0.f;
       b.y = 0.f;
     }
     s[padi(k)] = mkc(a.x - b.y, a.y + b.x);
     if (k > 0 && k < N / 2) s[padi(N - k)] = mkc(a.x + b.y, b.x - a.y);
+  };
+  for (int k = 2 * j; k < N / 2; k += 2 * Gm::NT) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 a2 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Qa + k));
+    const f32x4 b2 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Qb + k));
+    put(k, mkc(a2.x, a2.y), mkc(b2.x, b2.y));
+    put(k + 1, mkc(a2.z, a2.w), mkc(b2.z, b2.w));
   }
+  if (j == 0) put(N / 2, load_cf_nt(Qa + N / 2), load_cf_nt(Qb + N / 2));
   __syncthreads();
   fft_lds<N, +1>(s, j, tw);
   float bv = -INFINITY;
