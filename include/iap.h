@@ -104,7 +104,8 @@ int iap_apply_shift_u16(const uint16_t* in, uint16_t* out, int64_t n_frames, int
 
 /* utility.py:274-430 im_reg (translation) on a resident stack u16 [T][C][Z][Y][X]:
  * estimate on channel reg_channel (z-MIP), reference per ref_mode, apply to every channel and
- * plane.  out: same shape (must not alias in).  shifts_out: device f64 [T][2]. */
+ * plane.  out: same shape (must not alias in).  shifts_out: device f64 [T][2].  With IAP_REF_FIRST frame 0
+ * is the reference itself and gets the shift (0, 0) exactly (a copy), as IAP_REF_PREVIOUS copies frame 0. */
 int iap_im_reg_u16(const uint16_t* in, uint16_t* out, int64_t T, int C, int Z, int Y, int X,
                    int reg_channel, int ref_mode, int flags, double* shifts_out,
                    void* ws, size_t ws_bytes, void* stream);
