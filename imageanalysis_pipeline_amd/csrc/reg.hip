@@ -232,12 +232,12 @@ __global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_r2c_kernel
 //         (the TC columns x N rows of a workgroup form one contiguous block), because every
 //         moving frame re-reads it tile by tile: contiguous 16-byte-per-lane reads instead of
 //         32-byte row pieces.
-// mode 1: forward FFT, P = G * conj(F) * scale (DC = 0, optional /|P|) with G = Gref (tile-major),
-//         inverse FFT, store back to F in place (R unused).
+// mode 1: forward FFT, P = G * conj(F) * scale (DC = 0, optional /|P|) with G = Gref (tile-major; one for
+//         all frames, G_stride = 0, or one per frame), inverse FFT, store back to F in place (R unused).
 template <int N>
 __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_kernel(
-    cf* __restrict__ F, long long F_stride, const cf* __restrict__ Gref, cf* __restrict__ R, long long R_stride,
-    int Wp, const cf* __restrict__ tw, int mode, int normalize, float scale) {
+    cf* __restrict__ F, long long F_stride, const cf* __restrict__ Gref, long long G_stride, cf* __restrict__ R,
+    long long R_stride, int Wp, const cf* __restrict__ tw, int mode, int normalize, float scale) {
   using Gm = FftGeom<N>;
   constexpr int NTH = Gm::TC * Gm::CNT;
   extern __shared__ cf lds_c[];
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_kerne
     for (int m = 0; m < Gm::CE / 2; ++m) {
       const int idx = tid + m * NTH;
       const int pc = idx % HP, u = idx / HP;
-      const float4 f2 = *reinterpret_cast<const float4*>(Gref + (size_t)v0 * N + 2 * idx);   // tile-major: [u][cc]
+      const float4 f2 = *reinterpret_cast<const float4*>(Gref + (size_t)frame * G_stride + (size_t)v0 * N + 2 * idx);   // tile-major: [u][cc]
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const cf g = lds_c[(2 * pc + h) * Gm::CS + padi(u)];
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_kerne
       const int idx = tid + m * NTH;
       const int pc = idx % HP, u = idx / HP;
       const cf a = lds_c[(2 * pc) * Gm::CS + padi(u)], b2 = lds_c[(2 * pc + 1) * Gm::CS + padi(u)];
-      *reinterpret_cast<float4*>(R + (size_t)v0 * N + 2 * idx) = make_float4(a.x, a.y, b2.x, b2.y);
+      *reinterpret_cast<float4*>(R + (size_t)frame * R_stride + (size_t)v0 * N + 2 * idx) = make_float4(a.x, a.y, b2.x, b2.y);
     }
     return;
   }
@@ -1295,14 +1295,14 @@ static int launch_rows_r2c(const RegPlan& p, const void* src, int kind, long lon
   return IAP_OK;
 }
 
-static int launch_cols(const RegPlan& p, cf* F, long long F_stride, const cf* Gref, cf* R, long long R_stride, int n,
-                       const cf* tw_y, int mode, int normalize, hipStream_t st) {
+static int launch_cols(const RegPlan& p, cf* F, long long F_stride, const cf* Gref, long long G_stride, cf* R,
+                       long long R_stride, int n, const cf* tw_y, int mode, int normalize, hipStream_t st) {
   float scale = 1.0f / ((float)p.Py * (float)p.Px);
   IAP_FOR_N(p.Py, {
     using Gm = FftGeom<N>;
     size_t lds = (size_t)Gm::TC * Gm::CS * sizeof(cf);
     IAP_HIP(allow_lds(cols_kernel<N>, lds));
-    { ProfScope ps_(K_COLS, st); hipLaunchKernelGGL(cols_kernel<N>, dim3(p.col_blocks, n), dim3(Gm::TC * Gm::CNT), lds, st, F, F_stride, Gref, R,
+    { ProfScope ps_(K_COLS, st); hipLaunchKernelGGL(cols_kernel<N>, dim3(p.col_blocks, n), dim3(Gm::TC * Gm::CNT), lds, st, F, F_stride, Gref, G_stride, R,
                        R_stride, p.Wp, tw_y, mode, normalize, scale); }
   });
   IAP_LAUNCH_CHECK();
@@ -1334,7 +1334,7 @@ static int reg_init_tables(const RegPlan& p, RegWs& w, hipStream_t st) {
 static int reg_ref_spectrum(const RegPlan& p, RegWs& w, const void* ref, int kind, float in_scale, hipStream_t st) {
   int rc = launch_rows_r2c(p, ref, kind, 0, in_scale, w.F, 0, 1, w.tw_x, st);
   if (rc) return rc;
-  return launch_cols(p, w.F, 0, nullptr, w.refspec, 0, 1, w.tw_y, 0, 0, st);
+  return launch_cols(p, w.F, 0, nullptr, 0, w.refspec, 0, 1, w.tw_y, 0, 0, st);
 }
 
 // shifts for n moving planes (n <= w.batch) against w.refspec
@@ -1355,12 +1355,13 @@ static int upsample_capacity() {
 }
 
 static int reg_estimate_batch(const RegPlan& p, RegWs& w, const uint16_t* mov, long long mov_stride, int n, int flags,
-                              double* shifts, hipStream_t st) {
+                              double* shifts, hipStream_t st, const cf* gref = nullptr, long long g_stride = 0) {
   const long long fs = (long long)(align256(p.spec * 8) / 8);
   const bool up = flags & IAP_REG_UPSAMPLE;
   int rc = launch_rows_r2c(p, mov, 0, mov_stride, 1.0f, w.F, fs, n, w.tw_x, st);
   if (rc) return rc;
-  rc = launch_cols(p, w.F, fs, w.refspec, nullptr, 0, n, w.tw_y, 1, (flags & IAP_REG_NORMALIZE) ? 1 : 0, st);
+  rc = launch_cols(p, w.F, fs, gref ? gref : w.refspec, g_stride, nullptr, 0, n, w.tw_y, 1,
+                   (flags & IAP_REG_NORMALIZE) ? 1 : 0, st);
   if (rc) return rc;
   rc = launch_rows_c2r(p, w.F, fs, n, w.tw_x, w.pval, w.pidx, st);
   if (rc) return rc;
@@ -1474,6 +1475,55 @@ extern "C" int iap_reg_estimate_u16(const void* ref, int ref_kind, const uint16_
   for (int64_t f0 = 0; f0 < n; f0 += w.batch) {
     int nb = (int)(n - f0 < w.batch ? n - f0 : w.batch);
     rc = reg_estimate_batch(p, w, mov + f0 * mov_stride, mov_stride, nb, flags, shifts_out + 2 * f0, st);
+    if (rc) return rc;
+  }
+  return IAP_OK;
+}
+
+// Pairwise estimate (channel shift, utility.py:313-330: every plane against the same frame's plane of the
+// registration channel): the workspace is that of the plain estimate plus one reference spectrum per
+// frame of the batch.
+extern "C" size_t iap_reg_pairs_ws_bytes(int Y, int X, int batch) {
+  RegPlan p;
+  if (!make_plan(Y, X, p)) return 0;
+  if (batch < 1) batch = 1;
+  return reg_fixed_bytes(p) + (size_t)batch * (reg_frame_bytes(p, 1) + align256(p.spec * 8)) + 512;
+}
+
+extern "C" int iap_reg_estimate_pairs_u16(const uint16_t* ref, int64_t ref_stride, const uint16_t* mov,
+                                          int64_t mov_stride, int64_t n, int Y, int X, int flags, double* shifts_out,
+                                          void* ws, size_t ws_bytes, void* stream) {
+  IAP_REQUIRE(ref && mov && shifts_out && ws, IAP_E_ARG, "iap_reg_estimate_pairs_u16: null pointer");
+  IAP_REQUIRE(n > 0, IAP_E_ARG, "iap_reg_estimate_pairs_u16: n must be positive");
+  IAP_REQUIRE(n == 1 || (mov_stride >= (int64_t)Y * X && ref_stride >= (int64_t)Y * X), IAP_E_ARG,
+              "iap_reg_estimate_pairs_u16: stride smaller than a plane");
+  RegPlan p;
+  int rc = reg_check("iap_reg_estimate_pairs_u16", Y, X, p);
+  if (rc) return rc;
+  // split the workspace: per-frame spectra first, the plain estimate's layout in the rest
+  const size_t gs = align256(p.spec * 8), per = reg_frame_bytes(p, 1) + gs, fixed = reg_fixed_bytes(p);
+  IAP_REQUIRE(ws_bytes >= fixed + per + 512, IAP_E_WS, "iap_reg_estimate_pairs_u16: workspace of %zu bytes, need %zu",
+              ws_bytes, iap_reg_pairs_ws_bytes(Y, X, 1));
+  int batch = (int)((ws_bytes - fixed - 512) / per);
+  if (batch > 4096) batch = 4096;
+  char* base = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+  cf* gref = (cf*)base;
+  RegWs w;
+  IAP_REQUIRE(carve(base + (size_t)batch * gs, fixed + (size_t)batch * reg_frame_bytes(p, 1) + 256, p, 1, w) && w.batch >= 1,
+              IAP_E_WS, "iap_reg_estimate_pairs_u16: workspace too small");
+  if (w.batch > batch) w.batch = batch;
+  hipStream_t st = as_stream(stream);
+  rc = reg_init_tables(p, w, st);
+  if (rc) return rc;
+  const long long fs = (long long)(align256(p.spec * 8) / 8), g_stride = (long long)(gs / 8);
+  for (int64_t f0 = 0; f0 < n; f0 += w.batch) {
+    const int nb = (int)(n - f0 < w.batch ? n - f0 : w.batch);
+    // reference planes -> row spectra in F -> full spectra, one per frame
+    rc = launch_rows_r2c(p, ref + f0 * ref_stride, 0, ref_stride, 1.0f, w.F, fs, nb, w.tw_x, st);
+    if (rc) return rc;
+    rc = launch_cols(p, w.F, fs, nullptr, 0, gref, g_stride, nb, w.tw_y, 0, 0, st);
+    if (rc) return rc;
+    rc = reg_estimate_batch(p, w, mov + f0 * mov_stride, mov_stride, nb, flags, shifts_out + 2 * f0, st, gref, g_stride);
     if (rc) return rc;
   }
   return IAP_OK;

@@ -272,6 +272,62 @@ def estimate_shifts(ref: torch.Tensor, mov: torch.Tensor, upsample: bool = True,
     return shifts
 
 
+def estimate_pair_shifts(ref: torch.Tensor, mov: torch.Tensor, upsample: bool = True, normalize: bool = False,
+                         batch: int = DEFAULT_REG_BATCH) -> torch.Tensor:
+    """(dy, dx) for n independent pairs: ref (n, Y, X) u16 against mov (n, Y, X) u16, plane by plane.  Both may
+    be strided views along n (planes themselves contiguous).  Returns float64 (n, 2) on the device."""
+    for a in (ref, mov):          # strided along n is fine here, so no _need_cuda (it insists on contiguity)
+        if not a.is_cuda:
+            raise _lib.IapError("imageanalysis_pipeline_amd.ops needs device tensors: the HIP library is the "
+                                "only implementation (no CPU fallback)")
+    _u16(ref)
+    _u16(mov)
+    if ref.shape != mov.shape or ref.dim() != 3:
+        raise ValueError("ref and mov must both be (n, Y, X)")
+    n, y, x = mov.shape
+    for a in (ref, mov):
+        if a.stride(2) != 1 or a.stride(1) != x or (n > 1 and a.stride(0) < y * x):
+            raise ValueError("planes must be contiguous (a stride along n is allowed)")
+    lib = _lib.load()
+    nb = lib.iap_reg_pairs_ws_bytes(y, x, max(1, min(batch, n)))
+    if nb == 0:
+        raise ValueError(f"registration needs planes of at least 64x64, got {y}x{x}")
+    ws = _workspace(nb, mov.device)
+    shifts = torch.empty((n, 2), dtype=torch.float64, device=mov.device)
+    _lib.check(lib.iap_reg_estimate_pairs_u16(ref.data_ptr(), ref.stride(0) if n > 1 else y * x, mov.data_ptr(),
+                                              mov.stride(0) if n > 1 else y * x, n, y, x,
+                                              _reg_flags(upsample, normalize), shifts.data_ptr(), ws.data_ptr(),
+                                              ws.numel(), _stream()), "iap_reg_estimate_pairs_u16")
+    return shifts
+
+
+def chan_shift(stack: torch.Tensor, reg_channel: int, upsample: bool = True):
+    """The channel-shift pass of utility.py:313-330 on a resident stack u16 (T, C, Z, Y, X): every plane of
+    every other channel is registered against the same frame's and z's plane of ``reg_channel`` and warped
+    (``sr.register_transform(ref_plane, plane)``); the registration channel is copied.  Returns
+    (shifted stack, shifts f64 (T, C, Z, 2)).  Opt-in: the reference overwrites this pass's files in its
+    reg_ref pass, so the shim's im_reg does not run it."""
+    _need_cuda(stack)
+    _u16(stack)
+    if stack.dim() != 5:
+        raise ValueError("stack must be (T, C, Z, Y, X)")
+    stack = stack.contiguous()
+    t, c, z, y, x = stack.shape
+    if not 0 <= reg_channel < c:
+        raise ValueError(f"reg_channel {reg_channel} not in 0..{c - 1}")
+    shifts = torch.zeros((t, c, z, 2), dtype=torch.float64, device=stack.device)
+    for ch in range(c):
+        if ch == reg_channel:
+            continue
+        if z == 1:      # one strided run over the frames
+            shifts[:, ch, 0] = estimate_pair_shifts(stack[:, reg_channel, 0], stack[:, ch, 0], upsample=upsample)
+        else:           # the z planes of a frame are contiguous; frames are not evenly spaced with them
+            for f in range(t):
+                shifts[f, ch] = estimate_pair_shifts(stack[f, reg_channel], stack[f, ch], upsample=upsample)
+    out = apply_shifts(stack.view(t * c * z, 1, y, x), shifts.view(t * c * z, 2).contiguous())
+    return out.view(t, c, z, y, x), shifts
+
+
 def apply_shifts(stack: torch.Tensor, shifts: torch.Tensor) -> torch.Tensor:
     """StackReg.transform + clip + astype(uint16) (utility.py:351-355): stack u16 (T, ..., Y, X),
     shifts f64 (T, 2); every plane of frame f is warped by shifts[f]."""

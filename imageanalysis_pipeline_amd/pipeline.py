@@ -333,6 +333,17 @@ class Utility:
         Utility._stitch_pass(d, lambda i: master, thr, new_ids=False)
         return ops.to_numpy_u16(d).astype(np.asarray(masks).dtype)
 
+    # ------------------------------------------------------------------ channel shift (utility.py:313-330)
+    @staticmethod
+    def chan_shift_stack(stack, reg_channel):
+        """The arithmetic of the reference's chan_shift pass on an in-memory stack (T, C, Z, Y, X) u16: every
+        plane registered against the same frame's plane of channel index ``reg_channel`` and warped.  Opt-in:
+        im_reg does not run it, because the reference's reg_ref pass re-reads the raw folder and overwrites
+        its files (the pass never survives there).  Returns (stack, shifts (T, C, Z, 2))."""
+        d = ops.to_device_u16(np.ascontiguousarray(stack).astype(np.uint16), _device())
+        out, sh = ops.chan_shift(d, int(reg_channel))
+        return ops.to_numpy_u16(out), sh.cpu().numpy()
+
     # ------------------------------------------------------------------ track clean-up (experiments.py:195-221)
     @staticmethod
     def filter_mask_shapes(masks, shape_threshold=0.2):

@@ -95,6 +95,15 @@ int iap_reg_estimate_u16(const void* ref, int ref_kind, const uint16_t* mov, int
                          int64_t n, int Y, int X, int flags, double* shifts_out,
                          void* ws, size_t ws_bytes, void* stream);
 
+/* Channel shift (utility.py:313-330, sr.register_transform(ref_plane_of_reg_channel, plane) per frame,
+ * channel and z-plane): n independent (reference, moving) pairs, pair i = ref + i*ref_stride against
+ * mov + i*mov_stride; shifts_out f64 [n][2] as above.  Workspace: iap_reg_pairs_ws_bytes (the plain
+ * estimate's plus one reference spectrum per frame of the batch). */
+size_t iap_reg_pairs_ws_bytes(int Y, int X, int batch);
+int iap_reg_estimate_pairs_u16(const uint16_t* ref, int64_t ref_stride, const uint16_t* mov, int64_t mov_stride,
+                               int64_t n, int Y, int X, int flags, double* shifts_out,
+                               void* ws, size_t ws_bytes, void* stream);
+
 /* StackReg.transform + clip + astype(uint16) of utility.py:351-355 fused over a stack:
  * n_frames frames of planes_per_frame planes each; frame f is warped by shifts[f] (device f64
  * [n][2]): out[y][x] = cubic-spline(in)(y-dy, x-dx), outside -> 0, negatives -> 0, truncate,

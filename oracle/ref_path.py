@@ -412,6 +412,25 @@ def im_reg_stack(stack: np.ndarray, reg_channel: int = 0, reg_ref: str = "mean",
     return out, shifts
 
 
+def chan_shift_stack(stack: np.ndarray, reg_channel: int = 0, upsample: bool = True):
+    """utility.py:313-330: per frame, channel and z-plane ``sr.register_transform(ref_plane, plane)`` with
+    ref_plane the same frame's and z's plane of the registration channel (no MIP).  Returns (shifted u16
+    stack, shifts (T, C, Z, 2)); the registration channel's own planes come back unchanged (shift 0)."""
+    t, c, z, y, x = stack.shape
+    out = np.zeros_like(stack)
+    shifts = np.zeros((t, c, z, 2), dtype=np.float64)
+    for f in range(t):
+        for ch in range(c):
+            for zz in range(z):
+                if ch == reg_channel:
+                    out[f, ch, zz] = stack[f, ch, zz]
+                    continue
+                dy, dx = phase_shift(stack[f, reg_channel, zz].astype(np.float64), stack[f, ch, zz], upsample=upsample)
+                shifts[f, ch, zz] = (dy, dx)
+                out[f, ch, zz] = apply_shift(stack[f, ch, zz], dy, dx)
+    return out, shifts
+
+
 # --------------------------------------------------------------------------------------
 # a7/a8/a9: per-label measurement  (analysis.py:80,98,164-173; experiments.py:200-201)
 # --------------------------------------------------------------------------------------

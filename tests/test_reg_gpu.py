@@ -199,3 +199,38 @@ def test_errors(dev):
         ops.im_reg(big, reg_ref="last")      # utility.py:297-299
     with pytest.raises(ValueError):
         ops.im_reg(big, reg_channel=3)
+
+
+@pytest.mark.parametrize("z", [1, 2])
+def test_chan_shift_pairs(dev, z):
+    """a6 (utility.py:313-330): every plane against the same frame's plane of the registration channel --
+    integer offsets are recovered exactly and the warp is an exact copy; sub-pixel offsets within 0.01 px"""
+    from imageanalysis_pipeline_amd import ops
+    t, c, y, x = 3, 3, 128, 192
+    base, _ = _stack(t, 1, z, y, x, True, seed=31 + z)          # (t, 1, z, y, x), frames drift; channels copy it
+    offs = {1: (3, -5), 2: (-2, 7)}
+    st = np.zeros((t, c, z, y, x), np.uint16)
+    st[:, 0] = base[:, 0]
+    for ch, (oy, ox) in offs.items():
+        st[:, ch] = np.roll(base[:, 0], (oy, ox), axis=(-2, -1))
+    got, sh = ops.chan_shift(ops.to_device_u16(st, dev), 0, upsample=False)
+    exp, esh = O.chan_shift_stack(st, 0, upsample=False)
+    assert np.array_equal(sh.cpu().numpy(), esh)
+    for ch, (oy, ox) in offs.items():          # the injected offsets come back (to the pixel: cyclic roll vs. crop window)
+        assert np.abs(esh[:, ch] - (-oy, -ox)).max() <= 1
+    assert np.array_equal(ops.to_numpy_u16(got), exp)
+    got, sh = ops.chan_shift(ops.to_device_u16(st, dev), 0, upsample=True)
+    exp, esh = O.chan_shift_stack(st, 0, upsample=True)
+    assert np.abs(sh.cpu().numpy() - esh).max() <= 0.01
+    assert np.array_equal(ops.to_numpy_u16(got)[:, 0], st[:, 0])
+
+
+def test_pair_estimate_matches_single_reference(dev):
+    """n pairs sharing one reference plane give the shifts of the single-reference estimate, bit for bit"""
+    from imageanalysis_pipeline_amd import ops
+    st, _ = _stack(6, 1, 1, 128, 128, False, seed=5)
+    d = ops.to_device_u16(st, dev)
+    mov = d[:, 0, 0]
+    a = ops.estimate_shifts(mov[0], mov, batch=4)
+    b = ops.estimate_pair_shifts(mov[0:1].expand(6, -1, -1).contiguous(), mov, batch=4)
+    assert torch.equal(a, b)
