@@ -960,7 +960,7 @@ __global__ __launch_bounds__(256, AM_MIN_WAVES) void apply_shift_kernel(const ui
     u.hi = __builtin_amdgcn_readfirstlane(a.hi);
     u.whole = __builtin_amdgcn_readfirstlane(a.whole);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) u.w[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.w[i])));
+    for (int i = 0; i < 4; ++i) u.w[i] = a.w[i];   // the weights stay in vector registers (scalar ones are short here)
     return u;
   };
   const AxisParams ay = uniform(pay), ax = uniform(pax);
