@@ -251,22 +251,35 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_kerne
   // one row as one 16-byte access (half the memory instructions of an 8-byte-per-lane mapping).
   static_assert(Gm::TC % 2 == 0 && Gm::CE % 2 == 0, "column pairs");
   constexpr int HP = Gm::TC / 2;                 // column pairs per row
-#pragma unroll 4
-  for (int m = 0; m < Gm::CE / 2; ++m) {
-    const int idx = tid + m * NTH;               // pair index: (row u, pair pc)
-    const int pc = idx % HP, u = idx / HP;
-    const float4 w = *reinterpret_cast<const float4*>(Ff + (size_t)u * Wp + v0 + 2 * pc);
-    lds_c[(2 * pc) * Gm::CS + padi(u)] = mkc(w.x, w.y);
-    lds_c[(2 * pc + 1) * Gm::CS + padi(u)] = mkc(w.z, w.w);
+  {
+    float4 w[Gm::CE / 2];                        // all of the thread's loads in flight together
+#pragma unroll
+    for (int m = 0; m < Gm::CE / 2; ++m) {
+      const int idx = tid + m * NTH;             // pair index: (row u, pair pc)
+      w[m] = *reinterpret_cast<const float4*>(Ff + (size_t)(idx / HP) * Wp + v0 + 2 * (idx % HP));
+    }
+#pragma unroll
+    for (int m = 0; m < Gm::CE / 2; ++m) {
+      const int idx = tid + m * NTH;
+      const int pc = idx % HP, u = idx / HP;
+      lds_c[(2 * pc) * Gm::CS + padi(u)] = mkc(w[m].x, w[m].y);
+      lds_c[(2 * pc + 1) * Gm::CS + padi(u)] = mkc(w[m].z, w[m].w);
+    }
   }
   __syncthreads();
   fft_lds<N, -1, Gm::CE>(s, j, tw);
   if (mode == 1) {
-#pragma unroll 4
+    // the reference spectrum's block: all of this thread's values are requested at once (one round trip
+    // to L2 instead of one per value; the FFT's registers are free here)
+    float4 gr[Gm::CE / 2];
+#pragma unroll
+    for (int m = 0; m < Gm::CE / 2; ++m)
+      gr[m] = *reinterpret_cast<const float4*>(Gref + (size_t)frame * G_stride + (size_t)v0 * N + 2 * (tid + m * NTH));   // tile-major: [u][cc]
+#pragma unroll
     for (int m = 0; m < Gm::CE / 2; ++m) {
       const int idx = tid + m * NTH;
       const int pc = idx % HP, u = idx / HP;
-      const float4 f2 = *reinterpret_cast<const float4*>(Gref + (size_t)frame * G_stride + (size_t)v0 * N + 2 * idx);   // tile-major: [u][cc]
+      const float4 f2 = gr[m];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const cf g = lds_c[(2 * pc + h) * Gm::CS + padi(u)];
