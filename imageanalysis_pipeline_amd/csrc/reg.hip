@@ -102,9 +102,41 @@ __device__ __forceinline__ void dft8(cf* v) {
   v[7] = sub_si<SIGN>(e1, d);
 }
 
+// 16 points as 4 x 4: four 4-point transforms over the stride-4 groups, twiddles W16^(q k), four 4-point
+// transforms across the groups; X[k + 4 m] comes out of transform k at position m
+template <int SIGN>
+__device__ __forceinline__ void dft16(cf* v) {
+  constexpr float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
+  constexpr float sg = SIGN < 0 ? -1.f : 1.f;
+  cf a[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    a[q][0] = v[q]; a[q][1] = v[q + 4]; a[q][2] = v[q + 8]; a[q][3] = v[q + 12];
+    dft4<SIGN>(a[q]);
+  }
+  // a[q][k] *= W16^(q k), W16 = exp(SIGN 2 pi i / 16)
+  a[1][1] = cmul(a[1][1], mkc(c1, sg * s1));            // W^1
+  a[1][2] = cmul(a[1][2], mkc(h, sg * h));              // W^2
+  a[1][3] = cmul(a[1][3], mkc(s1, sg * c1));            // W^3
+  a[2][1] = cmul(a[2][1], mkc(h, sg * h));              // W^2
+  a[2][2] = add_si<SIGN>(mkc(0.f, 0.f), a[2][2]);       // W^4 = SIGN i
+  a[2][3] = cmul(a[2][3], mkc(-h, sg * h));             // W^6
+  a[3][1] = cmul(a[3][1], mkc(s1, sg * c1));            // W^3
+  a[3][2] = cmul(a[3][2], mkc(-h, sg * h));             // W^6
+  a[3][3] = cmul(a[3][3], mkc(-c1, -sg * s1));          // W^9 = -W^1
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    cf b[4] = {a[0][k], a[1][k], a[2][k], a[3][k]};
+    dft4<SIGN>(b);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) v[k + 4 * m] = b[m];
+  }
+}
+
 template <int R, int SIGN>
 __device__ __forceinline__ void dftR(cf* v) {
-  if constexpr (R == 8) dft8<SIGN>(v);
+  if constexpr (R == 16) dft16<SIGN>(v);
+  else if constexpr (R == 8) dft8<SIGN>(v);
   else if constexpr (R == 4) dft4<SIGN>(v);
   else dft2<SIGN>(v);
 }
@@ -150,7 +182,8 @@ template <int N, int E, int SIGN, int Ns>
 __device__ __forceinline__ void fft_rec(cf* s, int j, const cf* __restrict__ tw) {
   if constexpr (Ns < N) {
     constexpr int rem = N / Ns;
-    constexpr int R = rem >= 8 ? 8 : rem;
+    // 16-point passes where a thread holds 16 points (a pass less through LDS for N >= 256), else 8
+    constexpr int R = (E >= 16 && rem >= 16) ? 16 : (rem >= 8 ? 8 : rem);
     fft_pass<N, E, R, SIGN, Ns>(s, j, tw);
     fft_rec<N, E, SIGN, Ns * R>(s, j, tw);
   }
