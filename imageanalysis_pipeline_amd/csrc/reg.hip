@@ -57,7 +57,11 @@ __device__ __forceinline__ cf subi(cf c, cf d) {
 template <int SIGN> __device__ __forceinline__ cf add_si(cf c, cf d) { return SIGN < 0 ? subi(c, d) : addi(c, d); }
 template <int SIGN> __device__ __forceinline__ cf sub_si(cf c, cf d) { return SIGN < 0 ? addi(c, d) : subi(c, d); }
 
-__device__ __forceinline__ int padi(int i) { return i + (i >> 3); }
+// LDS index of sequence element i.  8 points per thread (radix-8 passes): one pad element per 8; 16 points per
+// thread (radix-16 passes): an XOR swizzle of the low five bits, conflict-free for every pass of that
+// structure in a 32-lane / 64-bank model (the padded form costs 2x there)
+template <int E>
+__device__ __forceinline__ int padi(int i) { return E >= 16 ? (i ^ ((i >> 4) & 31)) : i + (i >> 3); }
 
 template <int SIGN>
 __device__ __forceinline__ void dft2(cf* v) {
@@ -152,7 +156,7 @@ __device__ __forceinline__ void fft_pass(cf* s, int j, const cf* __restrict__ tw
   for (int b = 0; b < NB; ++b) {
     const int jj = j + b * NT;
 #pragma unroll
-    for (int r = 0; r < R; ++r) v[b][r] = s[padi(jj + r * (N / R))];
+    for (int r = 0; r < R; ++r) v[b][r] = s[padi<E>(jj + r * (N / R))];
     if (Ns > 1) {
       const int k = jj & (Ns - 1);
       cf w1 = tw[k * (N / (Ns * R))];
@@ -173,7 +177,7 @@ __device__ __forceinline__ void fft_pass(cf* s, int j, const cf* __restrict__ tw
     const int jj = j + b * NT;
     const int base = (jj / Ns) * (Ns * R) + (jj & (Ns - 1));
 #pragma unroll
-    for (int r = 0; r < R; ++r) s[padi(base + r * Ns)] = v[b][r];
+    for (int r = 0; r < R; ++r) s[padi<E>(base + r * Ns)] = v[b][r];
   }
   __syncthreads();
 }
@@ -240,12 +244,12 @@ __global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_r2c_kernel
     const uint16_t* p16 = reinterpret_cast<const uint16_t*>(src);
     u16x8 qa = load8(p16 + offa + 8 * j), qb = load8(p16 + offb + 8 * j);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s[padi(8 * j + k)] = mkc((float)qa.v[k] * in_scale, (float)qb.v[k] * in_scale);
+    for (int k = 0; k < 8; ++k) s[padi<8>(8 * j + k)] = mkc((float)qa.v[k] * in_scale, (float)qb.v[k] * in_scale);
   } else {
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       int n = j + m * Gm::NT;
-      s[padi(n)] = mkc(load_src(src, kind, offa + n) * in_scale, load_src(src, kind, offb + n) * in_scale);
+      s[padi<8>(n)] = mkc(load_src(src, kind, offa + n) * in_scale, load_src(src, kind, offb + n) * in_scale);
     }
   }
   __syncthreads();
@@ -253,8 +257,8 @@ __global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_r2c_kernel
   cf* Fa = F + (size_t)blockIdx.y * F_stride + (size_t)ra * Wp;
   cf* Fb = Fa + Wp;
   for (int k = j; k <= N / 2; k += Gm::NT) {
-    cf zk = s[padi(k)];
-    cf zn = s[padi((N - k) & (N - 1))];
+    cf zk = s[padi<8>(k)];
+    cf zn = s[padi<8>((N - k) & (N - 1))];
     Fa[k] = mkc(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
     Fb[k] = mkc(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
   }
@@ -295,8 +299,8 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_kerne
     for (int m = 0; m < Gm::CE / 2; ++m) {
       const int idx = tid + m * NTH;
       const int pc = idx % HP, u = idx / HP;
-      lds_c[(2 * pc) * Gm::CS + padi(u)] = mkc(w[m].x, w[m].y);
-      lds_c[(2 * pc + 1) * Gm::CS + padi(u)] = mkc(w[m].z, w[m].w);
+      lds_c[(2 * pc) * Gm::CS + padi<Gm::CE>(u)] = mkc(w[m].x, w[m].y);
+      lds_c[(2 * pc + 1) * Gm::CS + padi<Gm::CE>(u)] = mkc(w[m].z, w[m].w);
     }
   }
   __syncthreads();
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_kerne
       const float4 f2 = gr[m];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const cf g = lds_c[(2 * pc + h) * Gm::CS + padi(u)];
+        const cf g = lds_c[(2 * pc + h) * Gm::CS + padi<Gm::CE>(u)];
         const cf f = h ? mkc(f2.z, f2.w) : mkc(f2.x, f2.y);
         cf p = mkc((f.x * g.x + f.y * g.y) * scale, (f.y * g.x - f.x * g.y) * scale);
         if (normalize) {
@@ -325,7 +329,7 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_kerne
           p.y *= inv;
         }
         if (u == 0 && v0 + 2 * pc + h == 0) p = mkc(0.f, 0.f);
-        lds_c[(2 * pc + h) * Gm::CS + padi(u)] = p;
+        lds_c[(2 * pc + h) * Gm::CS + padi<Gm::CE>(u)] = p;
       }
     }
     __syncthreads();
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_kerne
     for (int m = 0; m < Gm::CE / 2; ++m) {
       const int idx = tid + m * NTH;
       const int pc = idx % HP, u = idx / HP;
-      const cf a = lds_c[(2 * pc) * Gm::CS + padi(u)], b2 = lds_c[(2 * pc + 1) * Gm::CS + padi(u)];
+      const cf a = lds_c[(2 * pc) * Gm::CS + padi<Gm::CE>(u)], b2 = lds_c[(2 * pc + 1) * Gm::CS + padi<Gm::CE>(u)];
       *reinterpret_cast<float4*>(R + (size_t)frame * R_stride + (size_t)v0 * N + 2 * idx) = make_float4(a.x, a.y, b2.x, b2.y);
     }
     return;
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_kerne
   for (int m = 0; m < Gm::CE / 2; ++m) {
     const int idx = tid + m * NTH;
     const int pc = idx % HP, u = idx / HP;
-    const cf a = lds_c[(2 * pc) * Gm::CS + padi(u)], b2 = lds_c[(2 * pc + 1) * Gm::CS + padi(u)];
+    const cf a = lds_c[(2 * pc) * Gm::CS + padi<Gm::CE>(u)], b2 = lds_c[(2 * pc + 1) * Gm::CS + padi<Gm::CE>(u)];
     *reinterpret_cast<float4*>(Ff + (size_t)u * Wp + v0 + 2 * pc) = make_float4(a.x, a.y, b2.x, b2.y);
   }
 }
@@ -396,8 +400,8 @@ __global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_c2r_argmax
       a.y = 0.f;
       b.y = 0.f;
     }
-    s[padi(k)] = mkc(a.x - b.y, a.y + b.x);
-    if (k > 0 && k < N / 2) s[padi(N - k)] = mkc(a.x + b.y, b.x - a.y);
+    s[padi<8>(k)] = mkc(a.x - b.y, a.y + b.x);
+    if (k > 0 && k < N / 2) s[padi<8>(N - k)] = mkc(a.x + b.y, b.x - a.y);
   };
   for (int k = 2 * j; k < N / 2; k += 2 * Gm::NT) {
     typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_c2r_argmax
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
     int n = j + m * Gm::NT;
-    cf z = s[padi(n)];
+    cf z = s[padi<8>(n)];
     amax_take(bv, bi, z.x, ra * N + n);
     amax_take(bv, bi, z.y, rb * N + n);
   }
