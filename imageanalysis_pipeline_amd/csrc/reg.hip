@@ -208,7 +208,7 @@ struct FftGeom {
   static constexpr int TC = (8192 / N) < 16 ? (8192 / N) : 16;  // columns per workgroup
   static constexpr int CE = N >= 128 ? 16 : 8;                // points per thread in the column kernel
   static constexpr int CNT = N / CE;                          // threads per column FFT
-  static constexpr int CS = PADN + 4;                         // LDS stride between columns
+  static constexpr int CS = PADN + 8;                         // LDS stride between columns: the column pairs a lane pair touches sit 16 bank pairs apart
 };
 
 __global__ void twiddle_kernel(cf* tw, int n) {
