@@ -123,11 +123,13 @@ __device__ __forceinline__ void smo_row(const f4& A, const f4& B, const f4& Cn, 
   const float gx3 = ln.fx_r * ((ln.edge_r ? B.hi.y : br) - B.hi.x);
   const v2f gx_lo = {gx0, B.hi.x - B.lo.x};
   const v2f gx_hi = {B.hi.y - B.lo.y, gx3};
-  const v2f n2_lo = pk_fma(gx_lo, gx_lo, gy_lo * gy_lo);
-  const v2f n2_hi = pk_fma(gx_hi, gx_hi, gy_hi * gy_hi);
-  // zero gradient -> 0 * rsq(tiny) = 0 (non-zero n2 is >= 1 on integer pixels, far above the floor)
-  const v2f inv_lo = {__builtin_amdgcn_rsqf(fmaxf(n2_lo.x, 1e-30f)), __builtin_amdgcn_rsqf(fmaxf(n2_lo.y, 1e-30f))};
-  const v2f inv_hi = {__builtin_amdgcn_rsqf(fmaxf(n2_hi.x, 1e-30f)), __builtin_amdgcn_rsqf(fmaxf(n2_hi.y, 1e-30f))};
+  // zero gradient -> 0 * rsq(tiny) = 0: the floor rides in the fused multiply-adds (n2 + 1e-30 == n2 for every
+  // non-zero n2 of integer pixels, which is >= 1)
+  const v2f tiny = {1e-30f, 1e-30f};
+  const v2f n2_lo = pk_fma(gx_lo, gx_lo, pk_fma(gy_lo, gy_lo, tiny));
+  const v2f n2_hi = pk_fma(gx_hi, gx_hi, pk_fma(gy_hi, gy_hi, tiny));
+  const v2f inv_lo = {__builtin_amdgcn_rsqf(n2_lo.x), __builtin_amdgcn_rsqf(n2_lo.y)};
+  const v2f inv_hi = {__builtin_amdgcn_rsqf(n2_hi.x), __builtin_amdgcn_rsqf(n2_hi.y)};
   const v2f ny_lo = gy_lo * inv_lo, ny_hi = gy_hi * inv_hi;
   const v2f nx_lo = gx_lo * inv_lo, nx_hi = gx_hi * inv_hi;
   // neighbours' columns: left lane's cols 1..3, right lane's cols 0..2
