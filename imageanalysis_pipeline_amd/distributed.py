@@ -139,11 +139,15 @@ def process_fov_timeblocks(load_block, n_frames: int, threshold: float, reg_ref:
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     frames = shard_frames(n_frames, rank, world)
     t0, t1 = frames.start, frames.stop
-    stack, labels = load_block(t0, t1)
-    bg, _, _ = ops.bg_smo(stack, threshold, out=stack)
-    tb, c, z, y, x = bg.shape
-    ch = bg[:, reg_channel]                                          # (tb, Z, Y, X)
-    planes = ops.mip(ch.contiguous()) if z > 1 else ch[:, 0].contiguous()
+    stack, labels = load_block(t0, t1)                               # a rank past the last frame gets (0, C, Z, Y, X)
+    tb, c, z, y, x = stack.shape
+    if tb:
+        bg, _, _ = ops.bg_smo(stack, threshold, out=stack)
+        ch = bg[:, reg_channel]                                      # (tb, Z, Y, X)
+        planes = ops.mip(ch.contiguous()) if z > 1 else ch[:, 0].contiguous()
+    else:                                                            # still takes part in the exchange and the gather
+        bg = stack
+        planes = torch.zeros((0, y, x), dtype=torch.uint16, device=stack.device)
     ref = reference_plane(planes, t0, n_frames, reg_ref, group)
     shifts = ops.estimate_shifts(ref, planes) if tb else torch.zeros((0, 2), dtype=torch.float64, device=bg.device)
     if reg_ref == "first" and t0 == 0 and tb:
