@@ -9,7 +9,8 @@
 //                    write back in place: Q[y][v], spatial along y, spectral along x
 //   K3 rows_c2r_argmax  inverse row FFT + wave-shuffle / LDS arg-max (correlation surface is
 //                    never written to HBM)
-//   K4 coarse_finish    arg-max over the per-workgroup partials -> signed integer shift
+//   K4 coarse peak      arg-max over the per-workgroup partials -> signed integer shift: done by K5's table
+//                    kernel (whole-pixel mode: coarse_finish, a launch of its own)
 //   K5 upsample_tables / upsample_partial  matrix-DFT of the cross-power spectrum on a 15x15 grid of
 //                    0.1 px offsets, evaluated from Q (the buffer K3 reads anyway, so the spectrum
 //                    itself is never written): periodic-sinc weights along y, +-m symmetric phases
@@ -430,6 +431,14 @@ __global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_c2r_argmax
 }
 
 // K4 ---------------------------------------------------------------------------------------
+// flat index of the peak -> signed integer shift (wrap at the half size, phase_cross_correlation's rule)
+__device__ __forceinline__ int2 coarse_from_index(int bi, int Py, int Px) {
+  if (bi == 0x7fffffff) bi = 0;  // all-NaN / empty surface: no shift
+  const int py = bi / Px, px = bi - py * Px;
+  return make_int2(py > Py / 2 ? py - Py : py, px > Px / 2 ? px - Px : px);
+}
+
+// whole-pixel mode only: with upsampling the table kernel of K5 does this reduction itself
 __global__ __launch_bounds__(256) void coarse_finish_kernel(const float* __restrict__ pval,
                                                             const int* __restrict__ pidx, int nparts, int Py, int Px,
                                                             int2* __restrict__ coarse, double* __restrict__ shifts,
@@ -442,14 +451,11 @@ __global__ __launch_bounds__(256) void coarse_finish_kernel(const float* __restr
     amax_take(bv, bi, pval[(size_t)blockIdx.x * nparts + k], pidx[(size_t)blockIdx.x * nparts + k]);
   block_argmax(bv, bi, shv, shi);
   if (threadIdx.x == 0) {
-    if (bi == 0x7fffffff) bi = 0;  // all-NaN / empty surface: no shift
-    int py = bi / Px, px = bi - py * Px;
-    int sy = py > Py / 2 ? py - Py : py;
-    int sx = px > Px / 2 ? px - Px : px;
-    coarse[blockIdx.x] = make_int2(sy, sx);
+    const int2 cs = coarse_from_index(bi, Py, Px);
+    coarse[blockIdx.x] = cs;
     if (write_shifts) {
-      shifts[2 * blockIdx.x] = (double)sy;
-      shifts[2 * blockIdx.x + 1] = (double)sx;
+      shifts[2 * blockIdx.x] = (double)cs.x;
+      shifts[2 * blockIdx.x + 1] = (double)cs.y;
     }
   }
 }
@@ -469,7 +475,7 @@ __global__ __launch_bounds__(256) void coarse_finish_kernel(const float* __restr
 constexpr int UP_N = 15;       // grid points per axis: offsets -0.7 .. 0.7
 constexpr int UP_HALF = 7;
 constexpr float UP_STEP = 0.1f;
-constexpr int UP_UB_MIN = 64;  // fewest spectrum rows a workgroup takes
+constexpr int UP_UB_MIN = 16;  // fewest spectrum rows a workgroup takes (reached when few frames are in flight)
 constexpr int UP_YS = 16;      // floats per row record   {Ks(y'_0 - y) .. Ks(y'_14 - y), (-1)^y / Py}  (one 64-byte scalar load)
 constexpr int UP_XS = 20;      // floats per column record {w base.x, w base.y, 0, 0 | 1, a1..a7 | b1..b7, 0}
 constexpr int UP_NV = UP_N * UP_N;  // 225 grid values
@@ -520,10 +526,13 @@ __device__ __forceinline__ v2f up_row_sum(int j, int sy, const v2f* acc) {
 }
 
 // Row and column records of every frame of the batch (the coarse shift enters the row weights
-// and the column base).  The threads that build row records also sum the Nyquist column
+// and the column base).  Every workgroup first reduces K3's per-workgroup maxima to the coarse peak
+// (a few hundred values; cheaper than a launch of its own) and the first one of a frame records it.  The threads that build row records also sum the Nyquist column
 // v = Px/2, which the main kernel's power-of-two column split leaves out: one partial (16 weighted
 // row sums) per workgroup.
-__global__ __launch_bounds__(256) void upsample_tables_kernel(int Py, int Px, int Wp, const int2* __restrict__ coarse,
+__global__ __launch_bounds__(256) void upsample_tables_kernel(int Py, int Px, int Wp, const float* __restrict__ pval,
+                                                              const int* __restrict__ pidx, int nparts,
+                                                              int2* __restrict__ coarse,
                                                               const cf* __restrict__ Q, long long Q_stride,
                                                               float* __restrict__ yrec, float* __restrict__ xrec,
                                                               float* __restrict__ nyq, int nyb) {
@@ -532,9 +541,23 @@ __global__ __launch_bounds__(256) void upsample_tables_kernel(int Py, int Px, in
   const int frame = blockIdx.y;
   const int tid = threadIdx.x;
   const int i = blockIdx.x * 256 + tid;
-  const int2 cs = coarse[frame];
+  __shared__ float shv[16];
+  __shared__ int shi[16];
+  __shared__ int2 peak;
+  {
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int k = tid; k < nparts; k += 256)
+      amax_take(bv, bi, pval[(size_t)frame * nparts + k], pidx[(size_t)frame * nparts + k]);
+    block_argmax(bv, bi, shv, shi);
+    if (tid == 0) {
+      peak = coarse_from_index(bi, Py, Px);
+      if (blockIdx.x == 0) coarse[frame] = peak;
+    }
+  }
   if (tid < UP_N) row_weight_consts(tid, Py, wk[tid]);
   __syncthreads();
+  const int2 cs = peak;
   v2f acc[UP_N + 1];
 #pragma unroll
   for (int j = 0; j <= UP_N; ++j) acc[j] = (v2f){0.f, 0.f};
@@ -1405,18 +1428,24 @@ static int upsample_capacity() {
 }
 
 static int reg_estimate_batch(const RegPlan& p, RegWs& w, const uint16_t* mov, long long mov_stride, int n, int flags,
-                              double* shifts, hipStream_t st, const cf* gref = nullptr, long long g_stride = 0) {
+                              double* shifts, hipStream_t st, const cf* gref = nullptr, long long g_stride = 0,
+                              cf* rows = nullptr) {
+  // rows != nullptr: the n row-pass spectra are already there (slots of w.F filled ahead of a serial loop)
   const long long fs = (long long)(align256(p.spec * 8) / 8);
   const bool up = flags & IAP_REG_UPSAMPLE;
-  int rc = launch_rows_r2c(p, mov, 0, mov_stride, 1.0f, w.F, fs, n, w.tw_x, st);
+  cf* F = rows ? rows : w.F;
+  int rc = rows ? IAP_OK : launch_rows_r2c(p, mov, 0, mov_stride, 1.0f, F, fs, n, w.tw_x, st);
   if (rc) return rc;
-  rc = launch_cols(p, w.F, fs, gref ? gref : w.refspec, g_stride, nullptr, 0, n, w.tw_y, 1,
+  rc = launch_cols(p, F, fs, gref ? gref : w.refspec, g_stride, nullptr, 0, n, w.tw_y, 1,
                    (flags & IAP_REG_NORMALIZE) ? 1 : 0, st);
   if (rc) return rc;
-  rc = launch_rows_c2r(p, w.F, fs, n, w.tw_x, w.pval, w.pidx, st);
+  rc = launch_rows_c2r(p, F, fs, n, w.tw_x, w.pval, w.pidx, st);
   if (rc) return rc;
-  { ProfScope ps_(K_COARSE, st); hipLaunchKernelGGL(coarse_finish_kernel, dim3(n), dim3(256), 0, st, (const float*)w.pval, (const int*)w.pidx,
-                     p.row_blocks, p.Py, p.Px, w.coarse, shifts, up ? 0 : 1); }
+  if (!up) {
+    ProfScope ps_(K_COARSE, st);
+    hipLaunchKernelGGL(coarse_finish_kernel, dim3(n), dim3(256), 0, st, (const float*)w.pval, (const int*)w.pidx,
+                       p.row_blocks, p.Py, p.Px, w.coarse, shifts, 1);
+  }
   if (up) {
     // row chunks (multiples of 4 rows) sized so that the whole launch is resident at once
     int nuc = std::min(p.nuc, std::max(1, upsample_capacity() / (n * p.ncg)));
@@ -1425,9 +1454,10 @@ static int reg_estimate_batch(const RegPlan& p, RegWs& w, const uint16_t* mov, l
     const int nch = p.ncg * nuc, nyb = (p.Py + 255) / 256;
     { ProfScope ps_(K_OTHER, st);
       hipLaunchKernelGGL(upsample_tables_kernel, dim3((p.Py + p.Wp + 255) / 256, n), dim3(256), 0, st, p.Py, p.Px, p.Wp,
-                         (const int2*)w.coarse, (const cf*)w.F, fs, w.yrec, w.xrec, w.nyq, nyb); }
+                         (const float*)w.pval, (const int*)w.pidx, p.row_blocks, w.coarse, (const cf*)F, fs, w.yrec,
+                         w.xrec, w.nyq, nyb); }
     { ProfScope ps_(K_UPSAMPLE, st);
-      hipLaunchKernelGGL(upsample_partial_kernel, dim3(nch, n), dim3(256), 0, st, (const cf*)w.F, fs, p.Wp, p.Py, p.Px,
+      hipLaunchKernelGGL(upsample_partial_kernel, dim3(nch, n), dim3(256), 0, st, (const cf*)F, fs, p.Wp, p.Py, p.Px,
                          p.ncg, ub, (const int2*)w.coarse, (const float*)w.yrec, (const float*)w.xrec, w.upart, nch); }
     { ProfScope ps_(K_UPFINISH, st); hipLaunchKernelGGL(upsample_finish_kernel, dim3(n), dim3(256), 0, st, (const float*)w.upart, nch,
                          (const float*)w.nyq, nyb, (const float*)w.xrec, p.Wp, p.Px,
@@ -1632,25 +1662,38 @@ extern "C" int iap_im_reg_u16(const uint16_t* in, uint16_t* out, int64_t T, int 
   if (ref_mode == IAP_REF_PREVIOUS) {
     IAP_HIP(hipMemcpyAsync(out, in, (size_t)frame_stride * 2, hipMemcpyDeviceToDevice, st));
     IAP_HIP(hipMemsetAsync(shifts_out, 0, 16, st));
-    for (long long f = 1; f < T; ++f) {
-      const uint16_t* refp;
-      if (Z == 1) {
-        refp = out + (f - 1) * frame_stride + chan_off;
-      } else {
-        rc = launch_mip(out + (f - 1) * frame_stride + chan_off, frame_stride, w.mip_ref, 1, Z, px, st);
-        if (rc) return rc;
-        refp = w.mip_ref;
-      }
-      rc = reg_ref_spectrum(p, w, refp, 0, 1.0f, st);
-      if (rc) return rc;
+    // The chain reference -> estimate -> warp is serial in time, the row pass over the raw moving planes is
+    // not: it runs ahead, one launch per group of frames, into slots 1.. of w.F (slot 0 is the reference's).
+    const long long fs = (long long)(align256(p.spec * 8) / 8);
+    const int ahead = w.batch - 1;
+    for (long long f0 = 1; f0 < T; f0 += std::max(ahead, 1)) {
+      const int nb = (int)std::min<long long>(std::max(ahead, 1), T - f0);
       const uint16_t* mp;
       long long ms;
-      rc = mov_planes(in, f, 1, mp, ms);
+      rc = mov_planes(in, f0, nb, mp, ms);
       if (rc) return rc;
-      rc = reg_estimate_batch(p, w, mp, ms, 1, flags, shifts_out + 2 * f, st);
-      if (rc) return rc;
-      rc = launch_apply(in + f * frame_stride, out + f * frame_stride, 1, ppf, Y, X, shifts_out + 2 * f, st);
-      if (rc) return rc;
+      if (ahead) {
+        rc = launch_rows_r2c(p, mp, 0, ms, 1.0f, w.F + fs, fs, nb, w.tw_x, st);
+        if (rc) return rc;
+      }
+      for (int k = 0; k < nb; ++k) {
+        const long long f = f0 + k;
+        const uint16_t* refp;
+        if (Z == 1) {
+          refp = out + (f - 1) * frame_stride + chan_off;
+        } else {
+          rc = launch_mip(out + (f - 1) * frame_stride + chan_off, frame_stride, w.mip_ref, 1, Z, px, st);
+          if (rc) return rc;
+          refp = w.mip_ref;
+        }
+        rc = reg_ref_spectrum(p, w, refp, 0, 1.0f, st);
+        if (rc) return rc;
+        rc = reg_estimate_batch(p, w, mp, ms, 1, flags, shifts_out + 2 * f, st, nullptr, 0,
+                                ahead ? w.F + (size_t)(k + 1) * fs : nullptr);
+        if (rc) return rc;
+        rc = launch_apply(in + f * frame_stride, out + f * frame_stride, 1, ppf, Y, X, shifts_out + 2 * f, st);
+        if (rc) return rc;
+      }
     }
     return IAP_OK;
   }
