@@ -272,8 +272,12 @@ __global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_r2c_kernel
 //         32-byte row pieces.
 // mode 1: forward FFT, P = G * conj(F) * scale (DC = 0, optional /|P|) with G = Gref (tile-major; one for
 //         all frames, G_stride = 0, or one per frame), inverse FFT, store back to F in place (R unused).
-template <int N>
-__global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_kernel(
+// mode 2: as mode 1, but Gref is the reference's ROW-pass spectrum in F's own layout: its column FFT runs
+//         in a second LDS tile of the same workgroup (the serial 'previous' chain: one launch fewer per
+//         frame; the launch passes twice the LDS).  An instantiation of its own (FUSED), so that the
+//         batch modes keep their register budget.
+template <int N, bool FUSED>
+__global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, FUSED ? 2 : 4) void cols_kernel(
     cf* __restrict__ F, long long F_stride, const cf* __restrict__ Gref, long long G_stride, cf* __restrict__ R,
     long long R_stride, int Wp, const cf* __restrict__ tw, int mode, int normalize, float scale) {
   using Gm = FftGeom<N>;
@@ -304,9 +308,50 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_kerne
       lds_c[(2 * pc + 1) * Gm::CS + padi<Gm::CE>(u)] = mkc(w[m].z, w[m].w);
     }
   }
+  cf* const lds_g = lds_c + Gm::TC * Gm::CS;     // mode 2: the reference's tile
+  if (FUSED) {
+    const cf* Gf = Gref + (size_t)frame * G_stride;
+    float4 w[Gm::CE / 2];
+#pragma unroll
+    for (int m = 0; m < Gm::CE / 2; ++m) {
+      const int idx = tid + m * NTH;
+      w[m] = *reinterpret_cast<const float4*>(Gf + (size_t)(idx / HP) * Wp + v0 + 2 * (idx % HP));
+    }
+#pragma unroll
+    for (int m = 0; m < Gm::CE / 2; ++m) {
+      const int idx = tid + m * NTH;
+      const int pc = idx % HP, u = idx / HP;
+      lds_g[(2 * pc) * Gm::CS + padi<Gm::CE>(u)] = mkc(w[m].x, w[m].y);
+      lds_g[(2 * pc + 1) * Gm::CS + padi<Gm::CE>(u)] = mkc(w[m].z, w[m].w);
+    }
+  }
   __syncthreads();
   fft_lds<N, -1, Gm::CE>(s, j, tw);
-  if (mode == 1) {
+  if (FUSED) {
+    fft_lds<N, -1, Gm::CE>(lds_g + c * Gm::CS, j, tw);
+#pragma unroll
+    for (int m = 0; m < Gm::CE / 2; ++m) {
+      const int idx = tid + m * NTH;
+      const int pc = idx % HP, u = idx / HP;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int at = (2 * pc + h) * Gm::CS + padi<Gm::CE>(u);
+        const cf g = lds_c[at], f = lds_g[at];
+        cf p = mkc((f.x * g.x + f.y * g.y) * scale, (f.y * g.x - f.x * g.y) * scale);
+        if (normalize) {
+          float m2 = p.x * p.x + p.y * p.y;
+          float inv = m2 > 0.f ? rsqrtf(m2) : 0.f;
+          p.x *= inv;
+          p.y *= inv;
+        }
+        if (u == 0 && v0 + 2 * pc + h == 0) p = mkc(0.f, 0.f);
+        lds_c[at] = p;
+      }
+    }
+    __syncthreads();
+    fft_lds<N, +1, Gm::CE>(s, j, tw);
+  }
+  if (!FUSED && mode == 1) {
     // the reference spectrum's block: all of this thread's values are requested at once (one round trip
     // to L2 instead of one per value; the FFT's registers are free here)
     float4 gr[Gm::CE / 2];
@@ -336,7 +381,7 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_kerne
     __syncthreads();
     fft_lds<N, +1, Gm::CE>(s, j, tw);
   }
-  if (mode == 0) {
+  if (!FUSED && mode == 0) {
 #pragma unroll 4
     for (int m = 0; m < Gm::CE / 2; ++m) {
       const int idx = tid + m * NTH;
@@ -1373,10 +1418,17 @@ static int launch_cols(const RegPlan& p, cf* F, long long F_stride, const cf* Gr
   float scale = 1.0f / ((float)p.Py * (float)p.Px);
   IAP_FOR_N(p.Py, {
     using Gm = FftGeom<N>;
-    size_t lds = (size_t)Gm::TC * Gm::CS * sizeof(cf);
-    IAP_HIP(allow_lds(cols_kernel<N>, lds));
-    { ProfScope ps_(K_COLS, st); hipLaunchKernelGGL(cols_kernel<N>, dim3(p.col_blocks, n), dim3(Gm::TC * Gm::CNT), lds, st, F, F_stride, Gref, G_stride, R,
-                       R_stride, p.Wp, tw_y, mode, normalize, scale); }
+    size_t lds = (size_t)Gm::TC * Gm::CS * sizeof(cf) * (mode == 2 ? 2 : 1);
+    ProfScope ps_(K_COLS, st);
+    if (mode == 2) {
+      IAP_HIP(allow_lds(cols_kernel<N, true>, lds));
+      hipLaunchKernelGGL((cols_kernel<N, true>), dim3(p.col_blocks, n), dim3(Gm::TC * Gm::CNT), lds, st, F, F_stride, Gref,
+                         G_stride, R, R_stride, p.Wp, tw_y, mode, normalize, scale);
+    } else {
+      IAP_HIP(allow_lds(cols_kernel<N, false>, lds));
+      hipLaunchKernelGGL((cols_kernel<N, false>), dim3(p.col_blocks, n), dim3(Gm::TC * Gm::CNT), lds, st, F, F_stride, Gref,
+                         G_stride, R, R_stride, p.Wp, tw_y, mode, normalize, scale);
+    }
   });
   IAP_LAUNCH_CHECK();
   return IAP_OK;
@@ -1429,15 +1481,17 @@ static int upsample_capacity() {
 
 static int reg_estimate_batch(const RegPlan& p, RegWs& w, const uint16_t* mov, long long mov_stride, int n, int flags,
                               double* shifts, hipStream_t st, const cf* gref = nullptr, long long g_stride = 0,
-                              cf* rows = nullptr) {
+                              cf* rows = nullptr, const cf* ref_rows = nullptr) {
   // rows != nullptr: the n row-pass spectra are already there (slots of w.F filled ahead of a serial loop)
+  // ref_rows != nullptr: the reference comes as its row-pass spectrum (cols_kernel mode 2), not as w.refspec
   const long long fs = (long long)(align256(p.spec * 8) / 8);
   const bool up = flags & IAP_REG_UPSAMPLE;
   cf* F = rows ? rows : w.F;
   int rc = rows ? IAP_OK : launch_rows_r2c(p, mov, 0, mov_stride, 1.0f, F, fs, n, w.tw_x, st);
   if (rc) return rc;
-  rc = launch_cols(p, F, fs, gref ? gref : w.refspec, g_stride, nullptr, 0, n, w.tw_y, 1,
-                   (flags & IAP_REG_NORMALIZE) ? 1 : 0, st);
+  rc = ref_rows ? launch_cols(p, F, fs, ref_rows, 0, nullptr, 0, n, w.tw_y, 2, (flags & IAP_REG_NORMALIZE) ? 1 : 0, st)
+                : launch_cols(p, F, fs, gref ? gref : w.refspec, g_stride, nullptr, 0, n, w.tw_y, 1,
+                              (flags & IAP_REG_NORMALIZE) ? 1 : 0, st);
   if (rc) return rc;
   rc = launch_rows_c2r(p, F, fs, n, w.tw_x, w.pval, w.pidx, st);
   if (rc) return rc;
@@ -1686,10 +1740,16 @@ extern "C" int iap_im_reg_u16(const uint16_t* in, uint16_t* out, int64_t T, int 
           if (rc) return rc;
           refp = w.mip_ref;
         }
-        rc = reg_ref_spectrum(p, w, refp, 0, 1.0f, st);
-        if (rc) return rc;
-        rc = reg_estimate_batch(p, w, mp, ms, 1, flags, shifts_out + 2 * f, st, nullptr, 0,
-                                ahead ? w.F + (size_t)(k + 1) * fs : nullptr);
+        if (ahead) {   // the reference's row pass into slot 0; its column FFT rides in the cross-power launch
+          rc = launch_rows_r2c(p, refp, 0, 0, 1.0f, w.F, 0, 1, w.tw_x, st);
+          if (rc) return rc;
+          rc = reg_estimate_batch(p, w, mp, ms, 1, flags, shifts_out + 2 * f, st, nullptr, 0,
+                                  w.F + (size_t)(k + 1) * fs, w.F);
+        } else {
+          rc = reg_ref_spectrum(p, w, refp, 0, 1.0f, st);
+          if (rc) return rc;
+          rc = reg_estimate_batch(p, w, mp, ms, 1, flags, shifts_out + 2 * f, st);
+        }
         if (rc) return rc;
         rc = launch_apply(in + f * frame_stride, out + f * frame_stride, 1, ppf, Y, X, shifts_out + 2 * f, st);
         if (rc) return rc;

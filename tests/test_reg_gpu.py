@@ -159,6 +159,20 @@ def test_im_reg_modes(dev, mode, integer):
                 assert diff.max() <= WARP_TOL
 
 
+def test_im_reg_previous_same_for_every_batch(dev):
+    """'previous' is serial in time; the workspace's frame slots only decide how far the moving planes' row
+    pass runs ahead (batch 1: not at all, the reference spectrum goes through its own launches).  Shifts
+    and planes do not depend on it, bit for bit."""
+    from imageanalysis_pipeline_amd import ops
+    st, _ = _stack(7, 2, 1, 128, 192, False, seed=23)
+    d = ops.to_device_u16(st, dev)
+    ref_out, ref_sh = ops.im_reg(d, reg_channel=0, reg_ref="previous", upsample=True, batch=1)
+    for batch in (2, 3, 16):
+        out, sh = ops.im_reg(d, reg_channel=0, reg_ref="previous", upsample=True, batch=batch)
+        assert torch.equal(sh, ref_sh), batch
+        assert torch.equal(out.view(torch.int16), ref_out.view(torch.int16)), batch
+
+
 def test_im_reg_zstack_mip(dev):
     from imageanalysis_pipeline_amd import ops
     st, _ = _stack(4, 2, 3, 128, 128, True, seed=13)
