@@ -773,8 +773,10 @@ extern "C" size_t iap_bg_smo_ws_bytes(int64_t n, int Y, int X) {
 extern "C" int iap_bg_smo_u16(const uint16_t* in, uint16_t* out, int64_t n, int Y, int X, float sigma, int size,
                               float threshold, int32_t* med2_out, int32_t* nbg_out, void* ws, size_t ws_bytes,
                               void* stream) {
-  int rc = check_plane_args("iap_bg_smo_u16", in, out, n, Y, X);
+  // out == NULL: levels only (med2_out), for callers that subtract on load (iap_im_reg_sub_u16)
+  int rc = check_plane_args("iap_bg_smo_u16", in, out ? (const void*)out : (const void*)in, n, Y, X);
   if (rc) return rc;
+  IAP_REQUIRE(out || med2_out, IAP_E_ARG, "iap_bg_smo_u16: without an output stack med2_out must be given");
   IAP_REQUIRE(size >= 1 && size <= 63, IAP_E_ARG, "iap_bg_smo_u16: size must be in 1..63");
   IAP_REQUIRE(size & 1, IAP_E_ARG, "iap_bg_smo_u16: size must be odd");
   IAP_REQUIRE(sigma >= 0.f, IAP_E_ARG, "iap_bg_smo_u16: sigma must be >= 0");
@@ -797,7 +799,7 @@ extern "C" int iap_bg_smo_u16(const uint16_t* in, uint16_t* out, int64_t n, int 
   for (int64_t p0 = 0; p0 < n; p0 += B) {
     int64_t nb = n - p0 < B ? n - p0 : B;
     const uint16_t* bin = in + p0 * px;
-    uint16_t* bout = out + p0 * px;
+    uint16_t* bout = out ? out + p0 * px : nullptr;
     IAP_HIP(hipMemsetAsync(hist, 0, (size_t)nb * HIST_WORDS * 4, st));
     if (sigma > 0.f) {
       rc = launch_gauss_reflect<uint16_t>(bin, ftmp, fsm, nb, Y, X, sigma, st);
@@ -812,7 +814,7 @@ extern "C" int iap_bg_smo_u16(const uint16_t* in, uint16_t* out, int64_t n, int 
     unsigned gx = (unsigned)((px / 8 + 255) / 256);
     if (gx > 256) gx = 256;
     if (gx == 0) gx = 1;
-    { ProfScope ps_(K_SUB, st); hipLaunchKernelGGL(sub_half_kernel, dim3(gx, (unsigned)nb), dim3(256), 0, st, bin, bout, (long long)px,
+    if (bout) { ProfScope ps_(K_SUB, st); hipLaunchKernelGGL(sub_half_kernel, dim3(gx, (unsigned)nb), dim3(256), 0, st, bin, bout, (long long)px,
                        (const int*)med2); }
     IAP_LAUNCH_CHECK();
   }

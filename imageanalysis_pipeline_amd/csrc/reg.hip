@@ -221,6 +221,15 @@ __global__ void twiddle_kernel(cf* tw, int n) {
   }
 }
 
+// Background level of a plane that is subtracted on load: a kernel that reads raw u16 pixels v of plane i
+// sees max(v - level, 0), which is what sub_half_kernel (bg.hip) would have stored for sub2 = 2 * background:
+// max(2 v - sub2, 0) >> 1 == max(v - ((sub2 + 1) >> 1), 0) for integers.  sub2 == nullptr: level 0.
+__device__ __forceinline__ int plane_level(const int* __restrict__ sub2, long long i) {
+  if (!sub2) return 0;
+  const int s = (sub2[i] + 1) >> 1;
+  return min(max(s, 0), 65535);
+}
+
 __device__ __forceinline__ float load_src(const void* __restrict__ p, int kind, size_t i) {
   if (kind == 0) return (float)reinterpret_cast<const uint16_t*>(p)[i];
   if (kind == 1) return (float)reinterpret_cast<const uint32_t*>(p)[i];
@@ -231,13 +240,15 @@ __device__ __forceinline__ float load_src(const void* __restrict__ p, int kind, 
 template <int N>
 __global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_r2c_kernel(
     const void* __restrict__ src, int kind, long long plane_stride, int srcX, int oy, int ox, float in_scale,
-    cf* __restrict__ F, long long F_stride, int Wp, const cf* __restrict__ tw, int vec) {
+    cf* __restrict__ F, long long F_stride, int Wp, const cf* __restrict__ tw, int vec,
+    const int* __restrict__ sub2, long long sub_stride) {
   using Gm = FftGeom<N>;
   extern __shared__ cf lds_c[];
   const int g = threadIdx.x / Gm::NT, j = threadIdx.x % Gm::NT;
   cf* s = lds_c + g * Gm::PADN;
   const int pair = blockIdx.x * Gm::G + g;
   const int ra = 2 * pair;
+  const int lv = kind == 0 ? plane_level(sub2, (long long)blockIdx.y * sub_stride) : 0;   // u16 sources only
   const size_t base = (size_t)blockIdx.y * plane_stride;
   const size_t offa = base + (size_t)(oy + ra) * srcX + ox;
   const size_t offb = offa + srcX;
@@ -245,12 +256,19 @@ __global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_r2c_kernel
     const uint16_t* p16 = reinterpret_cast<const uint16_t*>(src);
     u16x8 qa = load8(p16 + offa + 8 * j), qb = load8(p16 + offb + 8 * j);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) s[padi<8>(8 * j + k)] = mkc((float)qa.v[k] * in_scale, (float)qb.v[k] * in_scale);
+    for (int k = 0; k < 8; ++k)
+      s[padi<8>(8 * j + k)] = mkc((float)max((int)qa.v[k] - lv, 0) * in_scale, (float)max((int)qb.v[k] - lv, 0) * in_scale);
   } else {
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       int n = j + m * Gm::NT;
-      s[padi<8>(n)] = mkc(load_src(src, kind, offa + n) * in_scale, load_src(src, kind, offb + n) * in_scale);
+      // (exact in f32: pixel values and levels are integers below 2^16)
+      float a = load_src(src, kind, offa + n), b = load_src(src, kind, offb + n);
+      if (kind == 0) {
+        a = fmaxf(a - (float)lv, 0.f);
+        b = fmaxf(b - (float)lv, 0.f);
+      }
+      s[padi<8>(n)] = mkc(a * in_scale, b * in_scale);
     }
   }
   __syncthreads();
@@ -863,27 +881,32 @@ __global__ __launch_bounds__(256) void upsample_finish_kernel(const float* __res
 
 // MIP / plane sums -------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mip_kernel(const uint16_t* __restrict__ in, long long in_stride,
-                                                  uint16_t* __restrict__ out, int Z, long long px) {
+                                                  uint16_t* __restrict__ out, int Z, long long px,
+                                                  const int* __restrict__ sub2, long long sub_stride) {
+  // sub2: plane z of item i is read as max(v - level(sub2[i * sub_stride + z]), 0)
   const long long item = blockIdx.y;
   const uint16_t* p = in + item * in_stride;
   uint16_t* o = out + item * px;
   const long long nv = px >> 3;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv;
        i += (long long)gridDim.x * blockDim.x) {
-    u16x8 m = load8(p + i * 8);
-    for (int z = 1; z < Z; ++z) {
-      u16x8 v = load8(p + z * px + i * 8);
+    u16x8 m;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) m.v[k] = v.v[k] > m.v[k] ? v.v[k] : m.v[k];
+    for (int k = 0; k < 8; ++k) m.v[k] = 0;
+    for (int z = 0; z < Z; ++z) {
+      const u16x8 v = load8(p + z * px + i * 8);
+      const int lv = plane_level(sub2, item * sub_stride + z);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) m.v[k] = (uint16_t)max((int)m.v[k], (int)v.v[k] - lv);
     }
     store8(o + i * 8, m);
   }
   if (blockIdx.x == 0) {
     long long i = nv * 8 + threadIdx.x;
     if (i < px) {
-      uint16_t m = p[i];
-      for (int z = 1; z < Z; ++z) m = p[z * px + i] > m ? p[z * px + i] : m;
-      o[i] = m;
+      int m = 0;
+      for (int z = 0; z < Z; ++z) m = max(m, (int)p[z * px + i] - plane_level(sub2, item * sub_stride + z));
+      o[i] = (uint16_t)m;
     }
   }
 }
@@ -892,7 +915,8 @@ __global__ __launch_bounds__(256) void mip_kernel(const uint16_t* __restrict__ i
 // planes in flight
 __global__ __launch_bounds__(256) void accum_planes_kernel(const uint16_t* __restrict__ in, long long stride,
                                                            long long n, long long px, uint32_t* __restrict__ sum,
-                                                           int vec) {
+                                                           int vec, const int* __restrict__ sub2, long long sub_stride) {
+  // sub2: plane k is read as max(v - level(sub2[k * sub_stride]), 0)
   if (vec) {
     const long long nv = px >> 3;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv;
@@ -903,17 +927,21 @@ __global__ __launch_bounds__(256) void accum_planes_kernel(const uint16_t* __res
       long long k = 0;
       for (; k + 4 <= n; k += 4) {
         u16x8 v[4];
+        int lv[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = load8_nt(in + (k + q) * stride + i * 8);
 #pragma unroll
+        for (int q = 0; q < 4; ++q) lv[q] = plane_level(sub2, (k + q) * sub_stride);
+#pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) s[e] += v[q].v[e];
+          for (int e = 0; e < 8; ++e) s[e] += (uint32_t)max((int)v[q].v[e] - lv[q], 0);
       }
       for (; k < n; ++k) {
         const u16x8 v = load8_nt(in + k * stride + i * 8);
+        const int lv = plane_level(sub2, k * sub_stride);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s[e] += v.v[e];
+        for (int e = 0; e < 8; ++e) s[e] += (uint32_t)max((int)v.v[e] - lv, 0);
       }
       reinterpret_cast<uint4*>(sum)[2 * i] = make_uint4(s[0], s[1], s[2], s[3]);
       reinterpret_cast<uint4*>(sum)[2 * i + 1] = make_uint4(s[4], s[5], s[6], s[7]);
@@ -923,7 +951,7 @@ __global__ __launch_bounds__(256) void accum_planes_kernel(const uint16_t* __res
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < px;
        i += (long long)gridDim.x * blockDim.x) {
     uint32_t s = sum[i];
-    for (long long k = 0; k < n; ++k) s += in[k * stride + i];
+    for (long long k = 0; k < n; ++k) s += (uint32_t)max((int)in[k * stride + i] - plane_level(sub2, k * sub_stride), 0);
     sum[i] = s;
   }
 }
@@ -1049,7 +1077,8 @@ __device__ __forceinline__ int reflect_near(int i, int n) {
 __global__ __launch_bounds__(256, AM_MIN_WAVES) void apply_shift_kernel(const uint16_t* __restrict__ in,
                                                                         uint16_t* __restrict__ out,
                                                                         long long planes_per_frame, int Y, int X,
-                                                                        const double* __restrict__ shifts, int nty) {
+                                                                        const double* __restrict__ shifts, int nty,
+                                                                        const int* __restrict__ sub2) {
   constexpr int VPR = AP_TW / 8;                 // 16-byte vectors per staged row
   constexpr int LP = AP_PITCH / 8;               // ... per LDS row
   constexpr int NV = AM_TY * VPR / 256;          // vectors a thread stages per step
@@ -1064,6 +1093,12 @@ __global__ __launch_bounds__(256, AM_MIN_WAVES) void apply_shift_kernel(const ui
 #endif
   const long long plane = blockIdx.z;
   const long long frame = plane / planes_per_frame;
+  // background level subtracted as the samples are staged (two pixels per saturating packed subtract); 0 without sub2
+  const unsigned short lv = (unsigned short)__builtin_amdgcn_readfirstlane(plane_level(sub2, plane));
+  auto lower = [&](u32x4 v) {
+    typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+    return __builtin_bit_cast(u32x4, __builtin_elementwise_sub_sat(__builtin_bit_cast(us8, v), (us8)(lv)));
+  };
   if (tid < 2) {
     AxisParams a = axis_params(shifts[2 * frame + tid], tid == 0 ? Y : X);
     if (tid == 0) pay = a;
@@ -1131,7 +1166,7 @@ __global__ __launch_bounds__(256, AM_MIN_WAVES) void apply_shift_kernel(const ui
   auto stage = [&](int src0) {
     if (cols_inside) {
 #pragma unroll
-      for (int jv = 0; jv < NV; ++jv) tile[lds_off[jv]] = q[jv];
+      for (int jv = 0; jv < NV; ++jv) tile[lds_off[jv]] = lower(q[jv]);
       return;
     }
     const bool inside = src0 >= 0 && src0 + AM_TY <= Y;
@@ -1144,7 +1179,7 @@ __global__ __launch_bounds__(256, AM_MIN_WAVES) void apply_shift_kernel(const ui
       u32x4 w8 = q[jv];
       const int c0 = col0[jv] + zero;
       if (!(wide && c0 >= 0 && c0 + 8 <= X)) w8 = border_vec(row_off(src0 + rr[jv], inside), c0);
-      tile[lds_off[jv]] = w8;
+      tile[lds_off[jv]] = lower(w8);
     }
   };
   // x pass over `nrows` staged rows -> colp rows jbase ..: one wave per run pair (m, m+4) when nrows = 64
@@ -1192,7 +1227,7 @@ __global__ __launch_bounds__(256, AM_MIN_WAVES) void apply_shift_kernel(const ui
       u32x4 w8;
       if (wide && c0 >= 0 && c0 + 8 <= X) w8 = *reinterpret_cast<const u32x4_px*>(p + ro + c0);
       else w8 = border_vec(ro, c0);
-      tile[r * LP + v] = w8;
+      tile[r * LP + v] = lower(w8);
     }
     if (wide) preload(src0 + AM_HALO);
     __syncthreads();
@@ -1399,15 +1434,21 @@ static hipError_t allow_lds(K kernel, size_t bytes) {
                              (int)bytes);
 }
 
+// Levels subtracted on load (plane_level): plane i of a launch takes sub2[i * stride]; none by default.
+struct PlaneSub {
+  const int* sub2 = nullptr;
+  long long stride = 0;
+};
+
 static int launch_rows_r2c(const RegPlan& p, const void* src, int kind, long long plane_stride, float in_scale,
-                           cf* F, long long F_stride, int n, const cf* tw_x, hipStream_t st) {
+                           cf* F, long long F_stride, int n, const cf* tw_x, hipStream_t st, PlaneSub sub = {}) {
   const int vec = kind == 0 && aligned16(src) && p.X % 8 == 0 && p.ox % 8 == 0 && plane_stride % 8 == 0;
   IAP_FOR_N(p.Px, {
     using Gm = FftGeom<N>;
     size_t lds = (size_t)Gm::G * Gm::PADN * sizeof(cf);
     IAP_HIP(allow_lds(rows_r2c_kernel<N>, lds));
     { ProfScope ps_(K_ROWS_R2C, st); hipLaunchKernelGGL(rows_r2c_kernel<N>, dim3(p.row_blocks, n), dim3(Gm::G * Gm::NT), lds, st, src, kind,
-                       plane_stride, p.X, p.oy, p.ox, in_scale, F, F_stride, p.Wp, tw_x, vec); }
+                       plane_stride, p.X, p.oy, p.ox, in_scale, F, F_stride, p.Wp, tw_x, vec, sub.sub2, sub.stride); }
   });
   IAP_LAUNCH_CHECK();
   return IAP_OK;
@@ -1456,8 +1497,9 @@ static int reg_init_tables(const RegPlan& p, RegWs& w, hipStream_t st) {
 
 // full 2-D spectrum of the reference plane into w.refspec (tile-major, see cols_kernel); the row
 // pass goes through the first frame slot of w.F, which is free between batches
-static int reg_ref_spectrum(const RegPlan& p, RegWs& w, const void* ref, int kind, float in_scale, hipStream_t st) {
-  int rc = launch_rows_r2c(p, ref, kind, 0, in_scale, w.F, 0, 1, w.tw_x, st);
+static int reg_ref_spectrum(const RegPlan& p, RegWs& w, const void* ref, int kind, float in_scale, hipStream_t st,
+                            PlaneSub sub = {}) {
+  int rc = launch_rows_r2c(p, ref, kind, 0, in_scale, w.F, 0, 1, w.tw_x, st, sub);
   if (rc) return rc;
   return launch_cols(p, w.F, 0, nullptr, 0, w.refspec, 0, 1, w.tw_y, 0, 0, st);
 }
@@ -1481,13 +1523,13 @@ static int upsample_capacity() {
 
 static int reg_estimate_batch(const RegPlan& p, RegWs& w, const uint16_t* mov, long long mov_stride, int n, int flags,
                               double* shifts, hipStream_t st, const cf* gref = nullptr, long long g_stride = 0,
-                              cf* rows = nullptr, const cf* ref_rows = nullptr) {
+                              cf* rows = nullptr, const cf* ref_rows = nullptr, PlaneSub msub = {}) {
   // rows != nullptr: the n row-pass spectra are already there (slots of w.F filled ahead of a serial loop)
   // ref_rows != nullptr: the reference comes as its row-pass spectrum (cols_kernel mode 2), not as w.refspec
   const long long fs = (long long)(align256(p.spec * 8) / 8);
   const bool up = flags & IAP_REG_UPSAMPLE;
   cf* F = rows ? rows : w.F;
-  int rc = rows ? IAP_OK : launch_rows_r2c(p, mov, 0, mov_stride, 1.0f, F, fs, n, w.tw_x, st);
+  int rc = rows ? IAP_OK : launch_rows_r2c(p, mov, 0, mov_stride, 1.0f, F, fs, n, w.tw_x, st, msub);
   if (rc) return rc;
   rc = ref_rows ? launch_cols(p, F, fs, ref_rows, 0, nullptr, 0, n, w.tw_y, 2, (flags & IAP_REG_NORMALIZE) ? 1 : 0, st)
                 : launch_cols(p, F, fs, gref ? gref : w.refspec, g_stride, nullptr, 0, n, w.tw_y, 1,
@@ -1522,21 +1564,21 @@ static int reg_estimate_batch(const RegPlan& p, RegWs& w, const uint16_t* mov, l
 }
 
 static int launch_mip(const uint16_t* in, long long in_stride, uint16_t* out, long long n, int Z, long long px,
-                      hipStream_t st) {
+                      hipStream_t st, PlaneSub sub = {}) {
   unsigned gx = (unsigned)((px / 8 + 255) / 256);
   if (gx > 512) gx = 512;
   if (gx == 0) gx = 1;
   for (long long i0 = 0; i0 < n; i0 += 32768) {
     long long nb = n - i0 < 32768 ? n - i0 : 32768;
     { ProfScope ps_(K_MIP, st); hipLaunchKernelGGL(mip_kernel, dim3(gx, (unsigned)nb), dim3(256), 0, st, in + i0 * in_stride, in_stride,
-                       out + i0 * px, Z, px); }
+                       out + i0 * px, Z, px, sub.sub2 ? sub.sub2 + i0 * sub.stride : nullptr, sub.stride); }
   }
   IAP_LAUNCH_CHECK();
   return IAP_OK;
 }
 
 static int launch_apply(const uint16_t* in, uint16_t* out, long long n_frames, long long ppf, int Y, int X,
-                        const double* shifts, hipStream_t st) {
+                        const double* shifts, hipStream_t st, const int* sub2 = nullptr) {
   const int tiles_x = (X + AP_TX - 1) / AP_TX, tiles_y = (Y + AM_TY - 1) / AM_TY;
   // each workgroup walks `nty` steps down its strip.  Long walks amortise the 25-row lead-in, short ones keep
   // neighbouring strips close enough in time for the columns they share to be served by L2: 8 measured best
@@ -1554,7 +1596,8 @@ static int launch_apply(const uint16_t* in, uint16_t* out, long long n_frames, l
     grid.z = (unsigned)(nf * ppf);
     ProfScope ps_(K_APPLY, st);
     hipLaunchKernelGGL(apply_shift_kernel, grid, dim3(256), 0, st, in + (size_t)f0 * ppf * Y * X,
-                       out + (size_t)f0 * ppf * Y * X, ppf, Y, X, shifts + 2 * f0, nty);
+                       out + (size_t)f0 * ppf * Y * X, ppf, Y, X, shifts + 2 * f0, nty,
+                       sub2 ? sub2 + f0 * ppf : nullptr);
   }
   IAP_LAUNCH_CHECK();
   return IAP_OK;
@@ -1673,9 +1716,10 @@ extern "C" int iap_apply_shift_u16(const uint16_t* in, uint16_t* out, int64_t n_
   return launch_apply(in, out, n_frames, planes_per_frame, Y, X, shifts, as_stream(stream));
 }
 
-extern "C" int iap_im_reg_u16(const uint16_t* in, uint16_t* out, int64_t T, int C, int Z, int Y, int X,
-                              int reg_channel, int ref_mode, int flags, double* shifts_out, void* ws, size_t ws_bytes,
-                              void* stream) {
+// sub2 (device, one int per plane of the stack, or nullptr): every read of `in` sees max(v - sub2/2, 0)
+static int im_reg_impl(const uint16_t* in, uint16_t* out, int64_t T, int C, int Z, int Y, int X,
+                       int reg_channel, int ref_mode, int flags, const int* sub2, double* shifts_out, void* ws,
+                       size_t ws_bytes, void* stream) {
   IAP_REQUIRE(in && out && shifts_out && ws, IAP_E_ARG, "iap_im_reg_u16: null pointer");
   IAP_REQUIRE(in != out, IAP_E_ARG, "iap_im_reg_u16: out must not alias in");
   IAP_REQUIRE(T > 0 && C > 0 && Z > 0, IAP_E_ARG, "iap_im_reg_u16: non-positive size");
@@ -1700,22 +1744,40 @@ extern "C" int iap_im_reg_u16(const uint16_t* in, uint16_t* out, int64_t T, int 
   const long long frame_stride = ppf * px;
   const long long chan_off = (long long)reg_channel * Z * px;
 
-  // moving planes of frames [f0, f0+nb): either straight from the stack (Z == 1) or z-MIPs
-  auto mov_planes = [&](const uint16_t* stack, long long f0, int nb, const uint16_t*& mp, long long& ms) -> int {
+  // levels of the registration channel's planes from frame f0 on
+  auto chan_sub = [&](long long f0) {
+    PlaneSub s;
+    if (sub2) {
+      s.sub2 = sub2 + f0 * ppf + (long long)reg_channel * Z;
+      s.stride = ppf;
+    }
+    return s;
+  };
+  // moving planes of frames [f0, f0+nb): either straight from the stack (Z == 1; `msub`: what is left to
+  // subtract when they are read) or z-MIPs of the lowered planes
+  auto mov_planes = [&](const uint16_t* stack, long long f0, int nb, const uint16_t*& mp, long long& ms,
+                        PlaneSub& msub) -> int {
     if (Z == 1) {
       mp = stack + f0 * frame_stride + chan_off;
       ms = frame_stride;
+      msub = chan_sub(f0);
       return IAP_OK;
     }
-    int r = launch_mip(stack + f0 * frame_stride + chan_off, frame_stride, w.mip, nb, Z, px, st);
+    int r = launch_mip(stack + f0 * frame_stride + chan_off, frame_stride, w.mip, nb, Z, px, st, chan_sub(f0));
     mp = w.mip;
     ms = px;
+    msub = PlaneSub{};
     return r;
   };
 
   if (ref_mode == IAP_REF_PREVIOUS) {
-    IAP_HIP(hipMemcpyAsync(out, in, (size_t)frame_stride * 2, hipMemcpyDeviceToDevice, st));
     IAP_HIP(hipMemsetAsync(shifts_out, 0, 16, st));
+    if (sub2) {   // frame 0 is a copy of the lowered planes: the warp with a zero shift is exactly that
+      rc = launch_apply(in, out, 1, ppf, Y, X, shifts_out, st, sub2);
+      if (rc) return rc;
+    } else {
+      IAP_HIP(hipMemcpyAsync(out, in, (size_t)frame_stride * 2, hipMemcpyDeviceToDevice, st));
+    }
     // The chain reference -> estimate -> warp is serial in time, the row pass over the raw moving planes is
     // not: it runs ahead, one launch per group of frames, into slots 1.. of w.F (slot 0 is the reference's).
     const long long fs = (long long)(align256(p.spec * 8) / 8);
@@ -1724,10 +1786,11 @@ extern "C" int iap_im_reg_u16(const uint16_t* in, uint16_t* out, int64_t T, int 
       const int nb = (int)std::min<long long>(std::max(ahead, 1), T - f0);
       const uint16_t* mp;
       long long ms;
-      rc = mov_planes(in, f0, nb, mp, ms);
+      PlaneSub msub;
+      rc = mov_planes(in, f0, nb, mp, ms, msub);
       if (rc) return rc;
       if (ahead) {
-        rc = launch_rows_r2c(p, mp, 0, ms, 1.0f, w.F + fs, fs, nb, w.tw_x, st);
+        rc = launch_rows_r2c(p, mp, 0, ms, 1.0f, w.F + fs, fs, nb, w.tw_x, st, msub);
         if (rc) return rc;
       }
       for (int k = 0; k < nb; ++k) {
@@ -1748,10 +1811,11 @@ extern "C" int iap_im_reg_u16(const uint16_t* in, uint16_t* out, int64_t T, int 
         } else {
           rc = reg_ref_spectrum(p, w, refp, 0, 1.0f, st);
           if (rc) return rc;
-          rc = reg_estimate_batch(p, w, mp, ms, 1, flags, shifts_out + 2 * f, st);
+          rc = reg_estimate_batch(p, w, mp, ms, 1, flags, shifts_out + 2 * f, st, nullptr, 0, nullptr, nullptr, msub);
         }
         if (rc) return rc;
-        rc = launch_apply(in + f * frame_stride, out + f * frame_stride, 1, ppf, Y, X, shifts_out + 2 * f, st);
+        rc = launch_apply(in + f * frame_stride, out + f * frame_stride, 1, ppf, Y, X, shifts_out + 2 * f, st,
+                          sub2 ? sub2 + f * ppf : nullptr);
         if (rc) return rc;
       }
     }
@@ -1760,16 +1824,16 @@ extern "C" int iap_im_reg_u16(const uint16_t* in, uint16_t* out, int64_t T, int 
 
   if (ref_mode == IAP_REF_FIRST) {
     const uint16_t* mp;
-    long long ms;
+    PlaneSub rsub;
     if (Z == 1) {
       mp = in + chan_off;
+      rsub = chan_sub(0);
     } else {
-      rc = launch_mip(in + chan_off, frame_stride, w.mip_ref, 1, Z, px, st);
+      rc = launch_mip(in + chan_off, frame_stride, w.mip_ref, 1, Z, px, st, chan_sub(0));
       if (rc) return rc;
       mp = w.mip_ref;
     }
-    (void)ms;
-    rc = reg_ref_spectrum(p, w, mp, 0, 1.0f, st);
+    rc = reg_ref_spectrum(p, w, mp, 0, 1.0f, st, rsub);
     if (rc) return rc;
   } else {  // mean over T of the (MIP) planes: exact u32 sum, scaled by 1/T on load
     IAP_HIP(hipMemsetAsync(w.sum, 0, (size_t)px * 4, st));
@@ -1779,10 +1843,11 @@ extern "C" int iap_im_reg_u16(const uint16_t* in, uint16_t* out, int64_t T, int 
       int nb = (int)(T - f0 < w.batch ? T - f0 : w.batch);
       const uint16_t* mp;
       long long ms;
-      rc = mov_planes(in, f0, nb, mp, ms);
+      PlaneSub msub;
+      rc = mov_planes(in, f0, nb, mp, ms, msub);
       if (rc) return rc;
       const int vec = px % 8 == 0 && ms % 8 == 0 && aligned16(mp) && aligned16(w.sum);
-      { ProfScope ps_(K_ACCUM, st); hipLaunchKernelGGL(accum_planes_kernel, dim3(vec ? (unsigned)std::min<long long>((px / 8 + 255) / 256, 4096) : gx), dim3(256), 0, st, mp, ms, (long long)nb, px, w.sum, vec); }
+      { ProfScope ps_(K_ACCUM, st); hipLaunchKernelGGL(accum_planes_kernel, dim3(vec ? (unsigned)std::min<long long>((px / 8 + 255) / 256, 4096) : gx), dim3(256), 0, st, mp, ms, (long long)nb, px, w.sum, vec, msub.sub2, msub.stride); }
     }
     IAP_LAUNCH_CHECK();
     rc = reg_ref_spectrum(p, w, w.sum, 1, 1.0f / (float)T, st);
@@ -1792,13 +1857,28 @@ extern "C" int iap_im_reg_u16(const uint16_t* in, uint16_t* out, int64_t T, int 
     int nb = (int)(T - f0 < w.batch ? T - f0 : w.batch);
     const uint16_t* mp;
     long long ms;
-    rc = mov_planes(in, f0, nb, mp, ms);
+    PlaneSub msub;
+    rc = mov_planes(in, f0, nb, mp, ms, msub);
     if (rc) return rc;
-    rc = reg_estimate_batch(p, w, mp, ms, nb, flags, shifts_out + 2 * f0, st);
+    rc = reg_estimate_batch(p, w, mp, ms, nb, flags, shifts_out + 2 * f0, st, nullptr, 0, nullptr, nullptr, msub);
     if (rc) return rc;
   }
   // 'first': frame 0 is the reference itself, its shift is zero by definition (the estimate, summed in f32
   // from Q, lands within 1e-4 px of it; a non-zero remainder would push the plane's last row or column out)
   if (ref_mode == IAP_REF_FIRST) IAP_HIP(hipMemsetAsync(shifts_out, 0, 16, st));
-  return launch_apply(in, out, T, ppf, Y, X, shifts_out, st);
+  return launch_apply(in, out, T, ppf, Y, X, shifts_out, st, sub2);
+}
+
+extern "C" int iap_im_reg_u16(const uint16_t* in, uint16_t* out, int64_t T, int C, int Z, int Y, int X,
+                              int reg_channel, int ref_mode, int flags, double* shifts_out, void* ws, size_t ws_bytes,
+                              void* stream) {
+  return im_reg_impl(in, out, T, C, Z, Y, X, reg_channel, ref_mode, flags, nullptr, shifts_out, ws, ws_bytes, stream);
+}
+
+extern "C" int iap_im_reg_sub_u16(const uint16_t* in, uint16_t* out, int64_t T, int C, int Z, int Y, int X,
+                                  int reg_channel, int ref_mode, int flags, const int32_t* sub2, double* shifts_out,
+                                  void* ws, size_t ws_bytes, void* stream) {
+  IAP_REQUIRE(sub2, IAP_E_ARG, "iap_im_reg_sub_u16: sub2 is null (use iap_im_reg_u16)");
+  return im_reg_impl(in, out, T, C, Z, Y, X, reg_channel, ref_mode, flags, (const int*)sub2, shifts_out, ws, ws_bytes,
+                     stream);
 }

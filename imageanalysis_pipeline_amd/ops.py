@@ -195,6 +195,22 @@ def bg_smo(planes: torch.Tensor, threshold: float, sigma: float = 0.0, size: int
     return out, med2, nbg
 
 
+def bg_smo_levels(planes: torch.Tensor, threshold: float, sigma: float = 0.0, size: int = 7):
+    """The background levels of ``bg_smo`` without the subtracted stack: (med2 int32 (n,) = 2 * median of the
+    background pixels, nbg int32 (n,)).  ``im_reg(..., sub2=med2)`` subtracts them as it reads."""
+    _need_cuda(planes)
+    _u16(planes)
+    n, y, x = _planes(planes)
+    lib = _lib.load()
+    ws = _workspace(lib.iap_bg_smo_ws_bytes(n, y, x), planes.device)
+    med2 = torch.empty(n, dtype=torch.int32, device=planes.device)
+    nbg = torch.empty(n, dtype=torch.int32, device=planes.device)
+    _lib.check(lib.iap_bg_smo_u16(planes.data_ptr(), None, n, y, x, float(sigma), int(size), float(threshold),
+                                  med2.data_ptr(), nbg.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+               "iap_bg_smo_u16")
+    return med2, nbg
+
+
 def bg_manual(planes: torch.Tensor, roi, out: torch.Tensor | None = None):
     """utility.py:228-233: roi = (r0, c0, r1, c1) inclusive; returns (out, bg int32 (n,))."""
     _need_cuda(planes)
@@ -346,9 +362,12 @@ def apply_shifts(stack: torch.Tensor, shifts: torch.Tensor) -> torch.Tensor:
 
 
 def im_reg(stack: torch.Tensor, reg_channel: int = 0, reg_ref: str = "mean", upsample: bool = True,
-           normalize: bool = False, batch: int = DEFAULT_REG_BATCH, out: torch.Tensor | None = None):
+           normalize: bool = False, batch: int = DEFAULT_REG_BATCH, out: torch.Tensor | None = None,
+           sub2: torch.Tensor | None = None):
     """utility.py:274-430 (translation) on a resident stack u16 (T, C, Z, Y, X).
-    Returns (registered stack, shifts f64 (T, 2))."""
+    Returns (registered stack, shifts f64 (T, 2)).  ``sub2`` (int32, one per plane: ``bg_smo_levels``'s med2):
+    ``stack`` is the raw stack and the background is subtracted as the kernels read it; the result equals
+    ``im_reg(bg_smo(stack)[0])`` bit for bit, without the pass that writes the subtracted stack."""
     _need_cuda(stack)
     _u16(stack)
     if stack.dim() != 5:
@@ -364,6 +383,15 @@ def im_reg(stack: torch.Tensor, reg_channel: int = 0, reg_ref: str = "mean", ups
     if out is None:
         out = torch.empty_like(stack)
     shifts = torch.zeros((t, 2), dtype=torch.float64, device=stack.device)
+    if sub2 is not None:
+        _need_cuda(sub2)
+        if sub2.dtype != torch.int32 or sub2.numel() != t * c * z:
+            raise ValueError("sub2 must be int32 with one value per plane (T*C*Z)")
+        _lib.check(lib.iap_im_reg_sub_u16(stack.data_ptr(), out.data_ptr(), t, c, z, y, x, int(reg_channel),
+                                          REF_MODES[reg_ref], _reg_flags(upsample, normalize), sub2.data_ptr(),
+                                          shifts.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+                   "iap_im_reg_sub_u16")
+        return out, shifts
     _lib.check(lib.iap_im_reg_u16(stack.data_ptr(), out.data_ptr(), t, c, z, y, x, int(reg_channel),
                                   REF_MODES[reg_ref], _reg_flags(upsample, normalize), shifts.data_ptr(),
                                   ws.data_ptr(), ws.numel(), _stream()), "iap_im_reg_u16")

@@ -50,7 +50,9 @@ size_t iap_bg_smo_ws_bytes(int64_t n, int Y, int X);
  *   mask = SMO(plane) < threshold ; med = median(plane[mask]) ;
  *   out = trunc(max(plane - med, 0)) as u16.           in == out is allowed (in place).
  * med2_out (optional, device int32[n]) receives 2*median (half-integers are possible);
- * nbg_out (optional, device int32[n]) the number of background pixels. */
+ * nbg_out (optional, device int32[n]) the number of background pixels.
+ * out == NULL (med2_out required): levels only, nothing is written back -- for a caller that hands
+ * med2_out to iap_im_reg_sub_u16, which subtracts as it reads. */
 int iap_bg_smo_u16(const uint16_t* in, uint16_t* out, int64_t n, int Y, int X,
                    float sigma, int size, float threshold,
                    int32_t* med2_out, int32_t* nbg_out,
@@ -118,6 +120,15 @@ int iap_apply_shift_u16(const uint16_t* in, uint16_t* out, int64_t n_frames, int
 int iap_im_reg_u16(const uint16_t* in, uint16_t* out, int64_t T, int C, int Z, int Y, int X,
                    int reg_channel, int ref_mode, int flags, double* shifts_out,
                    void* ws, size_t ws_bytes, void* stream);
+
+/* core.py:99-112 pre_process_all runs smo_bg_sub (utility.py:255-264) and then im_reg (utility.py:274-430) over
+ * the same stack; with the stack resident the subtraction needs no pass of its own.  As iap_im_reg_u16, but `in`
+ * is the RAW stack and every kernel that reads it (row FFT, MIP, plane sum, warp) sees
+ * trunc(max(v - sub2[plane]/2, 0)), plane = (t*C + c)*Z + z: bit for bit what iap_bg_smo_u16 (sub2 = its
+ * med2_out) or iap_bg_const_u16 (sub2 = 2 * its bg_out) would have stored first.  sub2: device int32 [T*C*Z]. */
+int iap_im_reg_sub_u16(const uint16_t* in, uint16_t* out, int64_t T, int C, int Z, int Y, int X,
+                       int reg_channel, int ref_mode, int flags, const int32_t* sub2, double* shifts_out,
+                       void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ measurement ------ */
 

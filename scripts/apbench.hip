@@ -22,7 +22,7 @@ int main(int argc, char** argv) {
     hipMemcpyToSymbol(HIP_SYMBOL(g_ap_stamps), z, sizeof(z));
 #endif
     hipEventRecord(a);
-    hipLaunchKernelGGL(apply_shift_kernel, grid, dim3(256), 0, 0, in, out, 1LL, Y, X, sh, nty);
+    hipLaunchKernelGGL(apply_shift_kernel, grid, dim3(256), 0, 0, in, out, 1LL, Y, X, sh, nty, (const int*)nullptr);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     printf("nty=%d  %.2f us/plane", nty, ms * 1e3 / n);

@@ -173,6 +173,47 @@ def test_im_reg_previous_same_for_every_batch(dev):
         assert torch.equal(out.view(torch.int16), ref_out.view(torch.int16)), batch
 
 
+@pytest.mark.parametrize("mode", ["first", "mean", "previous"])
+@pytest.mark.parametrize("z", [1, 3])
+def test_im_reg_subtract_on_load(dev, mode, z):
+    """iap_im_reg_sub_u16 on the raw stack == iap_im_reg_u16 on the stack with the levels subtracted first
+    (the arithmetic of sub_half_kernel: max(2 v - sub2, 0) >> 1), bit for bit: even and odd sub2 (half-integer
+    medians), a zero level and one above every pixel of its plane."""
+    from imageanalysis_pipeline_amd import ops
+    st, _ = _stack(5, 2, z, 128, 192, False, seed=31)
+    d = ops.to_device_u16(st, dev)
+    rng = np.random.default_rng(5)
+    sub2 = rng.integers(0, 90, size=(5, 2, z)).astype(np.int32)
+    sub2[1, 0, 0] = 0
+    sub2[2, 1, z - 1] = 2 * 65535 + 1
+    sub2[3, 0, 0] |= 1
+    sub2[4, 0, 0] &= ~1
+    s2 = torch.from_numpy(sub2).to(dev)
+    lowered = (torch.clamp(2 * d.view(torch.int16).to(torch.int32).bitwise_and(0xffff) - s2[..., None, None], min=0) >> 1)
+    lowered = lowered.to(torch.int16).view(torch.uint16) if lowered.max() < 32768 else \
+        torch.from_numpy(lowered.cpu().numpy().astype(np.uint16)).to(dev)
+    exp_out, exp_sh = ops.im_reg(lowered.contiguous(), reg_channel=0, reg_ref=mode, upsample=True, batch=3)
+    out, sh = ops.im_reg(d, reg_channel=0, reg_ref=mode, upsample=True, batch=3, sub2=s2.reshape(-1))
+    assert torch.equal(sh, exp_sh)
+    assert torch.equal(out.view(torch.int16), exp_out.view(torch.int16))
+
+
+def test_bg_levels_then_subtract_on_load_equals_two_passes(dev):
+    """bg_smo_levels + im_reg(sub2=) == bg_smo + im_reg on a synthetic FOV, planes and shifts bit for bit;
+    the levels are bg_smo's own med2."""
+    from imageanalysis_pipeline_amd import ops
+    st, _ = _stack(4, 2, 1, 256, 256, False, seed=37)
+    d = ops.to_device_u16(st, dev)
+    thr = ops.smo_threshold((256, 256), seed=0, device=dev)
+    bg, med2, nbg = ops.bg_smo(d, thr)
+    lv, nb = ops.bg_smo_levels(d, thr)
+    assert torch.equal(lv, med2) and torch.equal(nb, nbg)
+    exp_out, exp_sh = ops.im_reg(bg, reg_channel=0, reg_ref="first")
+    out, sh = ops.im_reg(d, reg_channel=0, reg_ref="first", sub2=lv)
+    assert torch.equal(sh, exp_sh)
+    assert torch.equal(out.view(torch.int16), exp_out.view(torch.int16))
+
+
 def test_im_reg_zstack_mip(dev):
     from imageanalysis_pipeline_amd import ops
     st, _ = _stack(4, 2, 3, 128, 128, True, seed=13)
