@@ -2,8 +2,11 @@
 """Headline benchmark: Mpx/s through background-subtract + register + per-label measure.
 
 One "step" = one pass of the whole hot path over one resident field of view:
-    iap_bg_smo_u16 (raw -> bg)  ->  iap_im_reg_u16 (bg -> registered)  ->
+    iap_bg_smo_u16 (raw -> background level per plane)  ->  iap_im_reg_sub_u16 (raw - level -> registered)  ->
     iap_measure_labels_u16 + iap_measure_finalize (registered + labels -> per-cell tables)
+The background is subtracted as the registration kernels read the stack (same bits as writing the subtracted
+stack first; `--two-pass` runs that form: iap_bg_smo_u16 (raw -> bg) -> iap_im_reg_u16 (bg -> registered), and
+the default N=1 run reports its step time beside the headline as `two_pass_ms_per_step`).
 Workload at N=1: BASELINE.json configs[1] -- one FOV, 4 channels, 2048x2048 uint16, 500 frames
 with sub-pixel drift ("c2").  With --gpus N every rank holds its own FOV (weak scaling, FOV
 sharding, no data-path collective); the per-cell row tables are gathered to every rank with one
@@ -42,8 +45,9 @@ WORKLOADS = {
 }
 
 # algorithmic (compulsory) HBM bytes per stack pixel, SURVEY.md section 8(d)
-def stage_bytes_per_px(c: int) -> dict:
-    return {"bg": 4.0, "estimate": 2.0 / c, "apply": 4.0, "measure": 2.0 + 2.0 / c}
+def stage_bytes_per_px(c: int, two_pass: bool = False) -> dict:
+    # bg: read the stack (2 B) and, in the two-pass form only, write the subtracted stack (2 B)
+    return {"bg": 4.0 if two_pass else 2.0, "estimate": 2.0 / c, "apply": 4.0, "measure": 2.0 + 2.0 / c}
 
 
 STAGE_OF_KERNEL = {
@@ -89,18 +93,25 @@ def make_device_stack(t, c, z, y, x, n_cells, device, seed=0, subpixel=True):
 class Path:
     """The hot path on one resident FOV."""
 
-    def __init__(self, stack, labels, reg_ref="first", batch=16):
+    def __init__(self, stack, labels, reg_ref="first", batch=16, two_pass=False):
         self.raw, self.labels = stack, labels
-        self.bg = torch.empty_like(stack)
+        self.bg = None
         self.reg = torch.empty_like(stack)
-        self.reg_ref, self.batch = reg_ref, batch
+        self.reg_ref, self.batch, self.two_pass = reg_ref, batch, two_pass
         t, c, z, y, x = stack.shape
         self.thr = ops.smo_threshold((y, x), device=stack.device)
         self.n_labels = ops.max_label(labels) + 1
 
     def step(self):
-        ops.bg_smo(self.raw, self.thr, out=self.bg)
-        _, self.shifts = ops.im_reg(self.bg, 0, self.reg_ref, upsample=True, batch=self.batch, out=self.reg)
+        if self.two_pass:
+            if self.bg is None:
+                self.bg = torch.empty_like(self.raw)
+            ops.bg_smo(self.raw, self.thr, out=self.bg)
+            _, self.shifts = ops.im_reg(self.bg, 0, self.reg_ref, upsample=True, batch=self.batch, out=self.reg)
+        else:
+            levels, _ = ops.bg_smo_levels(self.raw, self.thr)
+            _, self.shifts = ops.im_reg(self.raw, 0, self.reg_ref, upsample=True, batch=self.batch, out=self.reg,
+                                        sub2=levels)
         acc = ops.measure_accumulate(self.reg, self.labels, self.n_labels)
         self.tables = ops.measure_finalize(acc)
         return self.tables
@@ -195,6 +206,7 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="override T")
     ap.add_argument("--reg-ref", default="first", choices=["first", "mean", "previous"])
     ap.add_argument("--batch", type=int, default=16, help="frames per registration launch group")
+    ap.add_argument("--two-pass", action="store_true", help="write the background-subtracted stack, then register it")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stage-report", action="store_true", help="also print a per-kernel table to stderr")
@@ -222,7 +234,7 @@ def main():
     if args.frames:
         t = args.frames
     stack, labels, _ = make_device_stack(t, c, z, y, x, n_cells, dev, seed=rank)
-    path = Path(stack, labels, args.reg_ref, args.batch)
+    path = Path(stack, labels, args.reg_ref, args.batch, args.two_pass)
     lib = _lib.load()
 
     def one_step():
@@ -258,7 +270,7 @@ def main():
 
     px_step = t * c * z * y * x
     value = px_step * world * args.steps / dt / 1e6
-    bpp = stage_bytes_per_px(c)
+    bpp = stage_bytes_per_px(c, args.two_pass)
     total_bpp = sum(bpp.values())
 
     roof = None
@@ -303,7 +315,9 @@ def main():
             "vs_baseline": None, "dtype": "u16", "data": "synthetic",
             "config": {"workload": f"{args.workload}: one FOV per GPU, T={t} C={c} Z={z} {y}x{x} uint16, sub-pixel drift, "
                                    f"{n_cells or 5041} labels/frame, reg_ref={args.reg_ref}",
-                       "stages": "bg_smo + im_reg(estimate+apply) + measure_labels", "parallelism": f"fov-shard x{world}"},
+                       "stages": "bg_smo + im_reg(estimate+apply) + measure_labels", "parallelism": f"fov-shard x{world}",
+                       "bg_subtraction": "written as a stack of its own, then registered" if args.two_pass else
+                                         "applied on load by the registration kernels (same bits, no intermediate stack)"},
             "hbm_frac_end_to_end": value * 1e6 / world * total_bpp / HBM_PEAK,
             "algorithmic_bytes_per_px": total_bpp,
         }
@@ -312,6 +326,18 @@ def main():
             out["stage_hbm_frac"] = {k: bpp[k] * px_step / (v / args.steps / 1e3) / HBM_PEAK for k, v in stages.items()}
         if roof:
             out["roofline"] = roof
+        if world == 1 and not args.two_pass:
+            # the same path with the subtracted stack written out and read back: same outputs, one more pass
+            path.two_pass = True
+            path.step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                path.step()
+            torch.cuda.synchronize()
+            out["two_pass_ms_per_step"] = (time.perf_counter() - t1) / args.steps * 1e3
+            path.two_pass = False
+            path.bg = None
         if world == 1:
             out["stream_copy_ceiling_GBps"] = stream_copy_ceiling(dev)
         if world == 1 and not args.no_cpu_baseline:
