@@ -719,7 +719,7 @@ static int launch_gauss_reflect(const T* in, float* tmp, float* out, int64_t n, 
   return IAP_OK;
 }
 
-constexpr int64_t BG_BATCH_BYTES = 1024ll << 20;  // planes per batch: long launches hide the march tail (C2 step: 512 MB 49.0, 1 GB 48.0, 2 GB 47.8 ms)
+constexpr int64_t BG_BATCH_BYTES = 2048ll << 20;  // planes per batch: long launches hide the march tail (C2 bg stage, levels only: 128 MB 18.2, 1 GB 8.95, 2 GB 8.5 ms)
 
 }  // namespace iap
 
