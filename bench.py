@@ -93,7 +93,7 @@ def make_device_stack(t, c, z, y, x, n_cells, device, seed=0, subpixel=True):
 class Path:
     """The hot path on one resident FOV."""
 
-    def __init__(self, stack, labels, reg_ref="first", batch=16, two_pass=False):
+    def __init__(self, stack, labels, reg_ref="first", batch=64, two_pass=False):
         self.raw, self.labels = stack, labels
         self.bg = None
         self.reg = torch.empty_like(stack)
@@ -205,7 +205,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=0, help="override T")
     ap.add_argument("--reg-ref", default="first", choices=["first", "mean", "previous"])
-    ap.add_argument("--batch", type=int, default=16, help="frames per registration launch group")
+    ap.add_argument("--batch", type=int, default=64, help="frames per registration launch group")
     ap.add_argument("--two-pass", action="store_true", help="write the background-subtracted stack, then register it")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")

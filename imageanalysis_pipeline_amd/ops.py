@@ -243,7 +243,7 @@ def gauss_blur(planes: torch.Tensor, ksize=(15, 15), sigma: float = 5.0) -> torc
 
 # ----------------------------------------------------------------------------- registration
 
-DEFAULT_REG_BATCH = 16
+DEFAULT_REG_BATCH = 64   # frames per launch group: C2 estimate 17.5 / 13.7 / 13.4 / 12.8 / 12.65 ms at 4 / 8 / 16 / 32 / 64
 
 
 def mip(stack: torch.Tensor) -> torch.Tensor:
@@ -389,12 +389,12 @@ def im_reg(stack: torch.Tensor, reg_channel: int = 0, reg_ref: str = "mean", ups
             raise ValueError("sub2 must be int32 with one value per plane (T*C*Z)")
         _lib.check(lib.iap_im_reg_sub_u16(stack.data_ptr(), out.data_ptr(), t, c, z, y, x, int(reg_channel),
                                           REF_MODES[reg_ref], _reg_flags(upsample, normalize), sub2.data_ptr(),
-                                          shifts.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+                                          shifts.data_ptr(), ws.data_ptr(), nb, _stream()),
                    "iap_im_reg_sub_u16")
         return out, shifts
     _lib.check(lib.iap_im_reg_u16(stack.data_ptr(), out.data_ptr(), t, c, z, y, x, int(reg_channel),
                                   REF_MODES[reg_ref], _reg_flags(upsample, normalize), shifts.data_ptr(),
-                                  ws.data_ptr(), ws.numel(), _stream()), "iap_im_reg_u16")
+                                  ws.data_ptr(), nb, _stream()), "iap_im_reg_u16")
     return out, shifts
 
 
