@@ -198,6 +198,24 @@ def test_im_reg_subtract_on_load(dev, mode, z):
     assert torch.equal(out.view(torch.int16), exp_out.view(torch.int16))
 
 
+@pytest.mark.parametrize("shape", [(100, 130), (65, 257), (333, 200)])
+def test_im_reg_subtract_on_load_ragged_planes(dev, shape):
+    """plane sizes that are not multiples of 8 (scalar row-pass loads, ragged strips and steps of the warp)"""
+    from imageanalysis_pipeline_amd import ops
+    y, x = shape
+    st, _ = _stack(4, 2, 1, y, x, False, seed=41)
+    d = ops.to_device_u16(st, dev)
+    sub2 = np.array([[[7]], [[120]]] * 4, dtype=np.int32).reshape(4, 2, 1) + np.arange(4, dtype=np.int32)[:, None, None]
+    s2 = torch.from_numpy(sub2).to(dev)
+    lowered = torch.clamp(2 * d.to(torch.int32) - s2[..., None, None], min=0) >> 1
+    lowered = lowered.to(torch.uint16).contiguous()
+    for mode in ("first", "mean"):
+        exp_out, exp_sh = ops.im_reg(lowered, reg_channel=1, reg_ref=mode)
+        out, sh = ops.im_reg(d, reg_channel=1, reg_ref=mode, sub2=s2.reshape(-1))
+        assert torch.equal(sh, exp_sh), mode
+        assert torch.equal(out.view(torch.int16), exp_out.view(torch.int16)), mode
+
+
 def test_bg_levels_then_subtract_on_load_equals_two_passes(dev):
     """bg_smo_levels + im_reg(sub2=) == bg_smo + im_reg on a synthetic FOV, planes and shifts bit for bit;
     the levels are bg_smo's own med2."""
