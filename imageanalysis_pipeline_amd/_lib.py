@@ -23,11 +23,13 @@ SIGNATURES = {
     "iap_bg_const_u16": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "iap_gauss_blur_u16": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp]),
     "iap_mip_u16": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "iap_mip_sub_u16": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
     "iap_reg_ws_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "iap_reg_estimate_u16": (_i32, [_vp, _i32, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "iap_reg_pairs_ws_bytes": (_sz, [_i32, _i32, _i32]),
     "iap_reg_estimate_pairs_u16": (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "iap_apply_shift_u16": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp]),
+    "iap_apply_shift_sub_u16": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
     "iap_im_reg_u16": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "iap_im_reg_sub_u16": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "iap_measure_labels_u16": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),

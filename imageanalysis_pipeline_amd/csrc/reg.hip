@@ -1618,6 +1618,20 @@ extern "C" int iap_mip_u16(const uint16_t* in, int64_t in_stride, uint16_t* out,
   return launch_mip(in, in_stride, out, n, Z, px, as_stream(stream));
 }
 
+extern "C" int iap_mip_sub_u16(const uint16_t* in, int64_t in_stride, uint16_t* out, int64_t n, int Z, int Y, int X,
+                               const int32_t* sub2, int64_t sub_stride, void* stream) {
+  IAP_REQUIRE(in && out && sub2, IAP_E_ARG, "iap_mip_sub_u16: null pointer");
+  IAP_REQUIRE(n > 0 && Z > 0 && Y > 0 && X > 0, IAP_E_ARG, "iap_mip_sub_u16: non-positive size");
+  long long px = (long long)Y * X;
+  IAP_REQUIRE(in_stride >= (int64_t)Z * px && sub_stride >= Z, IAP_E_ARG, "iap_mip_sub_u16: stride smaller than one item");
+  IAP_REQUIRE(aligned16(in) && aligned16(out) && (px % 8 == 0 || n == 1) && in_stride % 8 == 0, IAP_E_ALIGN,
+              "iap_mip_sub_u16: pointers must be 16-byte aligned and Y*X, in_stride multiples of 8");
+  PlaneSub s;
+  s.sub2 = (const int*)sub2;
+  s.stride = sub_stride;
+  return launch_mip(in, in_stride, out, n, Z, px, as_stream(stream), s);
+}
+
 extern "C" size_t iap_reg_ws_bytes(int Y, int X, int Z, int batch) {
   RegPlan p;
   if (Y <= 0 || X <= 0 || Z <= 0 || !make_plan(Y, X, p)) return 0;
@@ -1867,6 +1881,16 @@ static int im_reg_impl(const uint16_t* in, uint16_t* out, int64_t T, int C, int 
   // from Q, lands within 1e-4 px of it; a non-zero remainder would push the plane's last row or column out)
   if (ref_mode == IAP_REF_FIRST) IAP_HIP(hipMemsetAsync(shifts_out, 0, 16, st));
   return launch_apply(in, out, T, ppf, Y, X, shifts_out, st, sub2);
+}
+
+extern "C" int iap_apply_shift_sub_u16(const uint16_t* in, uint16_t* out, int64_t n_frames, int64_t planes_per_frame,
+                                       int Y, int X, const double* shifts, const int32_t* sub2, void* stream) {
+  IAP_REQUIRE(in && out && shifts && sub2, IAP_E_ARG, "iap_apply_shift_sub_u16: null pointer");
+  IAP_REQUIRE(in != out, IAP_E_ARG, "iap_apply_shift_sub_u16: in-place operation is not supported");
+  IAP_REQUIRE(n_frames > 0 && planes_per_frame > 0 && Y > 0 && X > 0, IAP_E_ARG,
+              "iap_apply_shift_sub_u16: non-positive size");
+  IAP_REQUIRE(planes_per_frame <= 65535, IAP_E_UNSUPPORTED, "iap_apply_shift_sub_u16: more than 65535 planes per frame");
+  return launch_apply(in, out, n_frames, planes_per_frame, Y, X, shifts, as_stream(stream), (const int*)sub2);
 }
 
 extern "C" int iap_im_reg_u16(const uint16_t* in, uint16_t* out, int64_t T, int C, int Z, int Y, int X,

@@ -141,18 +141,17 @@ def process_fov_timeblocks(load_block, n_frames: int, threshold: float, reg_ref:
     t0, t1 = frames.start, frames.stop
     stack, labels = load_block(t0, t1)                               # a rank past the last frame gets (0, C, Z, Y, X)
     tb, c, z, y, x = stack.shape
+    bg = stack                                                       # raw: the levels are subtracted on load
     if tb:
-        bg, _, _ = ops.bg_smo(stack, threshold, out=stack)
-        ch = bg[:, reg_channel]                                      # (tb, Z, Y, X)
-        planes = ops.mip(ch.contiguous()) if z > 1 else ch[:, 0].contiguous()
+        levels, _ = ops.bg_smo_levels(stack, threshold)
+        planes = ops.lowered_channel_mip(stack, reg_channel, levels)  # (tb, Y, X): the planes the estimate runs on
     else:                                                            # still takes part in the exchange and the gather
-        bg = stack
         planes = torch.zeros((0, y, x), dtype=torch.uint16, device=stack.device)
     ref = reference_plane(planes, t0, n_frames, reg_ref, group)
     shifts = ops.estimate_shifts(ref, planes) if tb else torch.zeros((0, 2), dtype=torch.float64, device=bg.device)
     if reg_ref == "first" and t0 == 0 and tb:
         shifts[0] = 0.0                                              # frame 0 is the reference itself (as ops.im_reg)
-    reg = ops.apply_shifts(bg, shifts) if tb else bg
+    reg = ops.apply_shifts(stack, shifts, sub2=levels) if tb else bg
     if tb:
         rows = pack_rows(ops.measure_finalize(ops.measure_accumulate(reg, labels)), fov)
         rows[:, 1] += float(t0)

@@ -257,6 +257,30 @@ def mip(stack: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def lowered_channel_mip(stack: torch.Tensor, channel: int, sub2: torch.Tensor) -> torch.Tensor:
+    """The registration planes of a RAW stack u16 (T, C, Z, Y, X) whose background levels ``sub2`` (int32, one per
+    plane, ``bg_smo_levels``) have not been subtracted yet: z-MIP (utility.py:335,341) of channel ``channel``'s
+    planes read as max(v - level, 0) -> u16 (T, Y, X), the planes ``im_reg(bg_smo(stack)[0])`` estimates on.  Reads
+    the channel in place (no copy of the strided view)."""
+    _need_cuda(stack, sub2)
+    _u16(stack)
+    if stack.dim() != 5:
+        raise ValueError("stack must be (T, C, Z, Y, X)")
+    t, c, z, y, x = stack.shape
+    if sub2.dtype != torch.int32 or sub2.numel() != t * c * z:
+        raise ValueError("sub2 must be int32 with one value per plane (T*C*Z)")
+    if not 0 <= channel < c:
+        raise ValueError(f"channel {channel} not in 0..{c - 1}")
+    out = torch.empty((t, y, x), dtype=torch.uint16, device=stack.device)
+    if t == 0:
+        return out
+    lib = _lib.load()
+    px = y * x
+    _lib.check(lib.iap_mip_sub_u16(stack.data_ptr() + 2 * channel * z * px, c * z * px, out.data_ptr(), t, z, y, x,
+                                   sub2.data_ptr() + 4 * channel * z, c * z, _stream()), "iap_mip_sub_u16")
+    return out
+
+
 def _reg_flags(upsample: bool, normalize: bool) -> int:
     return (REG_UPSAMPLE if upsample else 0) | (REG_NORMALIZE if normalize else 0)
 
@@ -344,9 +368,10 @@ def chan_shift(stack: torch.Tensor, reg_channel: int, upsample: bool = True):
     return out.view(t, c, z, y, x), shifts
 
 
-def apply_shifts(stack: torch.Tensor, shifts: torch.Tensor) -> torch.Tensor:
+def apply_shifts(stack: torch.Tensor, shifts: torch.Tensor, sub2: torch.Tensor | None = None) -> torch.Tensor:
     """StackReg.transform + clip + astype(uint16) (utility.py:351-355): stack u16 (T, ..., Y, X),
-    shifts f64 (T, 2); every plane of frame f is warped by shifts[f]."""
+    shifts f64 (T, 2); every plane of frame f is warped by shifts[f].  ``sub2`` (int32, one per plane): the
+    stack is raw and its background levels are subtracted as the planes are read (see ``im_reg``)."""
     _need_cuda(stack, shifts)
     _u16(stack)
     if shifts.dtype != torch.float64 or shifts.shape != (stack.shape[0], 2):
@@ -356,6 +381,13 @@ def apply_shifts(stack: torch.Tensor, shifts: torch.Tensor) -> torch.Tensor:
     ppf = stack.numel() // (t * y * x)
     out = torch.empty_like(stack)
     lib = _lib.load()
+    if sub2 is not None:
+        _need_cuda(sub2)
+        if sub2.dtype != torch.int32 or sub2.numel() != t * ppf:
+            raise ValueError("sub2 must be int32 with one value per plane")
+        _lib.check(lib.iap_apply_shift_sub_u16(stack.data_ptr(), out.data_ptr(), t, ppf, y, x, shifts.data_ptr(),
+                                               sub2.data_ptr(), _stream()), "iap_apply_shift_sub_u16")
+        return out
     _lib.check(lib.iap_apply_shift_u16(stack.data_ptr(), out.data_ptr(), t, ppf, y, x, shifts.data_ptr(), _stream()),
                "iap_apply_shift_u16")
     return out

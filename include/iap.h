@@ -84,6 +84,11 @@ int iap_gauss_blur_u16(const uint16_t* in, uint16_t* out, int64_t n, int Y, int 
 int iap_mip_u16(const uint16_t* in, int64_t in_stride, uint16_t* out, int64_t n, int Z, int Y, int X,
                 void* stream);
 
+/* The same over planes read as trunc(max(v - sub2/2, 0)) (see iap_im_reg_sub_u16): plane z of item i takes
+ * sub2[i * sub_stride + z].  With Z == 1 this is the subtracted copy of one plane per item. */
+int iap_mip_sub_u16(const uint16_t* in, int64_t in_stride, uint16_t* out, int64_t n, int Z, int Y, int X,
+                    const int32_t* sub2, int64_t sub_stride, void* stream);
+
 /* Workspace bytes for iap_reg_estimate_u16 / iap_im_reg_u16 processing `batch` frames per
  * launch group (batch >= 1).  Y, X are plane sizes; the FFT window is the centred
  * power-of-two crop (<= 4096) of each axis. */
@@ -112,6 +117,11 @@ int iap_reg_estimate_pairs_u16(const uint16_t* ref, int64_t ref_stride, const ui
  * saturate at 65535.  Integer shifts are exact copies.  in != out. */
 int iap_apply_shift_u16(const uint16_t* in, uint16_t* out, int64_t n_frames, int64_t planes_per_frame,
                         int Y, int X, const double* shifts, void* stream);
+
+/* iap_apply_shift_u16 over planes read as trunc(max(v - sub2/2, 0)), sub2: device int32 [n_frames * planes_per_frame]
+ * (see iap_im_reg_sub_u16; used where estimate and warp are separate calls, e.g. time-block sharding). */
+int iap_apply_shift_sub_u16(const uint16_t* in, uint16_t* out, int64_t n_frames, int64_t planes_per_frame,
+                            int Y, int X, const double* shifts, const int32_t* sub2, void* stream);
 
 /* utility.py:274-430 im_reg (translation) on a resident stack u16 [T][C][Z][Y][X]:
  * estimate on channel reg_channel (z-MIP), reference per ref_mode, apply to every channel and

@@ -216,6 +216,24 @@ def test_im_reg_subtract_on_load_ragged_planes(dev, shape):
         assert torch.equal(out.view(torch.int16), exp_out.view(torch.int16)), mode
 
 
+@pytest.mark.parametrize("z", [1, 2])
+def test_mip_and_warp_subtract_on_load(dev, z):
+    """iap_mip_sub_u16 / iap_apply_shift_sub_u16 on raw planes == the plain entry points on planes lowered first"""
+    from imageanalysis_pipeline_amd import ops
+    rng = np.random.default_rng(43 + z)
+    st = rng.integers(0, 65536, size=(4, 3, z, 96, 136)).astype(np.uint16)
+    d = ops.to_device_u16(st, dev)
+    sub2 = rng.integers(0, 2 * 40000, size=(4, 3, z)).astype(np.int32)
+    s2 = torch.from_numpy(sub2).to(dev)
+    lowered = (torch.clamp(2 * d.to(torch.int32) - s2[..., None, None], min=0) >> 1).to(torch.uint16).contiguous()
+    got = ops.lowered_channel_mip(d, 1, s2.reshape(-1))
+    assert torch.equal(got.view(torch.int16), ops.mip(lowered[:, 1].contiguous()).view(torch.int16))
+    sh = torch.tensor([(0.0, 0.0), (1.25, -2.5), (-3.0, 4.0), (0.5, 0.0)], dtype=torch.float64, device=dev)
+    a = ops.apply_shifts(d, sh, sub2=s2.reshape(-1))
+    b = ops.apply_shifts(lowered, sh)
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+
+
 def test_bg_levels_then_subtract_on_load_equals_two_passes(dev):
     """bg_smo_levels + im_reg(sub2=) == bg_smo + im_reg on a synthetic FOV, planes and shifts bit for bit;
     the levels are bg_smo's own med2."""
