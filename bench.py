@@ -93,7 +93,7 @@ def make_device_stack(t, c, z, y, x, n_cells, device, seed=0, subpixel=True):
 class Path:
     """The hot path on one resident FOV."""
 
-    def __init__(self, stack, labels, reg_ref="first", batch=64, two_pass=False):
+    def __init__(self, stack, labels, reg_ref="mean", batch=64, two_pass=False):
         self.raw, self.labels = stack, labels
         self.bg = None
         self.reg = torch.empty_like(stack)
@@ -170,7 +170,7 @@ def stream_copy_ceiling(dev, nbytes=1 << 30):
     return 2.0 * nbytes * 5 / (e0.elapsed_time(e1) / 1e3) / 1e9
 
 
-def cpu_baseline(y, x, c, n_cells, budget_frames=6):
+def cpu_baseline(y, x, c, n_cells, budget_frames=6, reg_ref="mean"):
     """The oracle (numpy restatement of the reference CPU path) on a bounded sample of the workload:
     `budget_frames` frames x C channels of the same plane size, same stages."""
     from oracle import ref_path as O
@@ -179,7 +179,7 @@ def cpu_baseline(y, x, c, n_cells, budget_frames=6):
         synth.make_dense_labels(y, x)[None, None].repeat(budget_frames, 0)
     thr = 0.05
     t0 = time.perf_counter()
-    O.run_path(st, lab, thr, reg_ref="first")
+    O.run_path(st, lab, thr, reg_ref=reg_ref)
     dt = time.perf_counter() - t0
     px = st.size
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
@@ -204,7 +204,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=0, help="override T")
-    ap.add_argument("--reg-ref", default="first", choices=["first", "mean", "previous"])
+    ap.add_argument("--reg-ref", default="mean", choices=["first", "mean", "previous"],
+                    help="reference frame of the registration; 'mean' is the reference's default (core.py:77) and what its notebook passes")
     ap.add_argument("--batch", type=int, default=64, help="frames per registration launch group")
     ap.add_argument("--two-pass", action="store_true", help="write the background-subtracted stack, then register it")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -341,7 +342,7 @@ def main():
         if world == 1:
             out["stream_copy_ceiling_GBps"] = stream_copy_ceiling(dev)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(y, x, c, n_cells or 0)
+            out["cpu_baseline"] = cpu_baseline(y, x, c, n_cells or 0, reg_ref=args.reg_ref)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
