@@ -784,7 +784,14 @@ extern "C" int iap_bg_smo_u16(const uint16_t* in, uint16_t* out, int64_t n, int 
   IAP_REQUIRE(ws_bytes >= iap_bg_smo_ws_bytes(n, Y, X), IAP_E_WS,
               "iap_bg_smo_u16: workspace of %zu bytes, need %zu", ws_bytes, iap_bg_smo_ws_bytes(n, Y, X));
   hipStream_t st = as_stream(stream);
-  const int64_t B = bg_batch_planes(n, Y, X);
+  int64_t B = bg_batch_planes(n, Y, X);
+  if (sigma == 0.f && !out) {
+    // levels only and no float planes to keep: the whole workspace can hold histograms, so one launch takes as
+    // many planes as fit and the march kernel's tail is paid once instead of once per batch (C2: 8.66 -> 8.3 ms;
+    // with the subtraction pass behind every batch the smaller batches measured 0.2 ms better)
+    const int64_t fit = (int64_t)((ws_bytes - 256) / ((size_t)HIST_WORDS * 4 + 16));
+    B = std::max(B, std::min(std::min(n, fit), (int64_t)65535));
+  }
   const int64_t px = (int64_t)Y * X;
   char* w = (char*)ws;
   unsigned* hist = (unsigned*)w;
