@@ -680,8 +680,11 @@ static int pick_band(int Y, int64_t n) {
   // every band re-primes its 7-row ring (6 rows: 4.7 % at 128 rows, 9 % at 64); ~3072 waves are resident
   // (3 per SIMD), so bands shrink only while fewer than ~4 rounds of waves would be in flight.
   // Measured on C2 (128 planes a launch): 64 rows 14.85, 128 rows 14.26, 256 rows 14.26, 512 rows 15.4 ms/step
+  // Launches over a whole stack (levels-only calls: 2000 planes on C2) have rounds to spare and take taller bands:
+  // 128 rows 8.36, 256 rows 8.04, 512 rows 7.99 ms/step.
   int band = 128;
   while (band > 16 && n * ((Y + band - 1) / band) * 9 < 12000) band >>= 1;
+  while (band < 512 && n * ((Y + 2 * band - 1) / (2 * band)) * 9 >= 60000) band <<= 1;
   return band;
 }
 
