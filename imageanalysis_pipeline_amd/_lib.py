@@ -51,6 +51,7 @@ SIGNATURES = {
     "iap_tiff_read_u16": (_i32, [C.POINTER(C.c_char_p), _i64, _vp, _i32, _i32, _i32]),
     "iap_tiff_write_u16": (_i32, [C.POINTER(C.c_char_p), _i64, _vp, _i32, _i32, _i32]),
     "iap_prof_enable": (None, [_i32]),
+    "iap_prof_select": (None, [_i32]),
     "iap_prof_kernel_count": (_i32, []),
     "iap_prof_kernel_name": (C.c_char_p, [_i32]),
     "iap_prof_collect": (_i32, [_i32, C.POINTER(C.c_double), C.POINTER(_i64)]),

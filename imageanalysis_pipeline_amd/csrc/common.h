@@ -47,15 +47,16 @@ enum KernelId {
   K_UPFINISH, K_APPLY, K_MEASURE, K_MEASURE_FIN, K_MIP, K_ACCUM, K_GAUSS, K_ROI, K_OTHER, K_COUNT
 };
 extern bool g_prof_on;
+extern int g_prof_only;   // kernel id the recording is restricted to, -1: every kernel
 void prof_mark(int kid, hipStream_t st, bool start);
 struct ProfScope {
   int kid;
   hipStream_t st;
   ProfScope(int k, hipStream_t s) : kid(k), st(s) {
-    if (g_prof_on) prof_mark(kid, st, true);
+    if (g_prof_on && (g_prof_only < 0 || g_prof_only == kid)) prof_mark(kid, st, true);
   }
   ~ProfScope() {
-    if (g_prof_on) prof_mark(kid, st, false);
+    if (g_prof_on && (g_prof_only < 0 || g_prof_only == kid)) prof_mark(kid, st, false);
   }
 };
 

@@ -17,6 +17,7 @@ void set_error(const char* fmt, ...) {
 
 namespace iap {
 bool g_prof_on = false;
+int g_prof_only = -1;
 namespace {
 struct ProfRec {
   int kid;
@@ -68,6 +69,11 @@ extern "C" void iap_prof_enable(int on) {
   }
   iap::g_recs.clear();
   iap::g_prof_on = on != 0;
+}
+
+extern "C" void iap_prof_select(int kernel_id) {
+  std::lock_guard<std::mutex> lk(iap::g_prof_mu);
+  iap::g_prof_only = (kernel_id >= 0 && kernel_id < iap::K_COUNT) ? kernel_id : -1;
 }
 
 extern "C" int iap_prof_kernel_count(void) { return iap::K_COUNT; }

@@ -243,6 +243,9 @@ int iap_tiff_write_u16(const char* const* paths, int64_t n, const uint16_t* src,
  * recording, iap_prof_enable(0) stops; iap_prof_collect synchronises the recorded events and
  * returns the summed duration and launch count of one kernel id (0 .. iap_prof_kernel_count()-1). */
 void iap_prof_enable(int on);
+/* Restrict the recording to one kernel id (-1: every kernel, the default): a timed run then carries two events per
+ * launch of that kernel only. */
+void iap_prof_select(int kernel_id);
 int iap_prof_kernel_count(void);
 const char* iap_prof_kernel_name(int kernel_id);
 int iap_prof_collect(int kernel_id, double* total_ms, int64_t* launches);
