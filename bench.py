@@ -13,9 +13,10 @@ sharding, no data-path collective); the per-cell row tables are gathered to ever
 RCCL all_gather inside the timed step.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` for the
-dominant kernel (HIP-event timing of every kernel launch of the timed steps, collected through
-iap_prof_*) and `cpu_baseline` (the numpy oracle = restated reference CPU path, timed on this
-host on a bounded sample of the same workload).
+dominant kernel (HIP events round each of its launches in the timed steps, on the stream it is
+launched on, collected through iap_prof_*; one step profiled in full before the timed region
+names that kernel and fills the stage table) and `cpu_baseline` (the numpy oracle = restated
+reference CPU path, timed on this host on a bounded sample of the same workload).
 """
 from __future__ import annotations
 
