@@ -17,8 +17,9 @@ _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size
 SIGNATURES = {
     "iap_version": (C.c_char_p, []),
     "iap_last_error": (C.c_char_p, []),
-    "iap_smo_image": (_i32, [_vp, _i32, _vp, _i64, _i32, _i32, _f32, _i32, _vp]),
-    "iap_bg_smo_ws_bytes": (_sz, [_i64, _i32, _i32]),
+    "iap_smo_image_ws_bytes": (_sz, [_i64, _i32, _i32, _f32]),
+    "iap_smo_image": (_i32, [_vp, _i32, _vp, _i64, _i32, _i32, _f32, _i32, _vp, _sz, _vp]),
+    "iap_bg_smo_ws_bytes": (_sz, [_i64, _i32, _i32, _f32]),
     "iap_bg_smo_u16": (_i32, [_vp, _vp, _i64, _i32, _i32, _f32, _i32, _f32, _vp, _vp, _vp, _sz, _vp]),
     "iap_bg_const_u16": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "iap_gauss_blur_u16": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp]),

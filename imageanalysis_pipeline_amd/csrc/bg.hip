@@ -737,17 +737,32 @@ static int check_plane_args(const char* fn, const void* in, const void* out, int
   return IAP_OK;
 }
 
+extern "C" size_t iap_smo_image_ws_bytes(int64_t n, int Y, int X, float sigma) {
+  if (n <= 0 || Y <= 0 || X <= 0 || !(sigma > 0.f)) return 0;
+  return (size_t)n * Y * X * 8 + 256;   // two float planes per plane: after the y pass, after the x pass
+}
+
 extern "C" int iap_smo_image(const void* in, int in_kind, float* out, int64_t n, int Y, int X, float sigma,
-                             int size, void* stream) {
+                             int size, void* ws, size_t ws_bytes, void* stream) {
   int rc = check_plane_args("iap_smo_image", in, out, n, Y, X);
   if (rc) return rc;
   IAP_REQUIRE(in_kind == 0 || in_kind == 1, IAP_E_ARG, "iap_smo_image: in_kind must be 0 (u16) or 1 (f32)");
   IAP_REQUIRE(size >= 1 && size <= 63, IAP_E_ARG, "iap_smo_image: size must be in 1..63");
   IAP_REQUIRE(size & 1, IAP_E_ARG, "iap_smo_image: size must be odd");
-  IAP_REQUIRE(sigma == 0.f, IAP_E_UNSUPPORTED,
-              "iap_smo_image: sigma > 0 needs scratch; use iap_bg_smo_u16 (which carries a workspace)");
+  IAP_REQUIRE(sigma >= 0.f, IAP_E_ARG, "iap_smo_image: sigma must be >= 0");
   IAP_REQUIRE(n <= 65535, IAP_E_UNSUPPORTED, "iap_smo_image: n must be <= 65535");
   hipStream_t st = as_stream(stream);
+  if (sigma > 0.f) {   // scipy gaussian_filter (reflect, truncate 4) first, as SMO(sigma=...) does
+    IAP_REQUIRE(ws && aligned16(ws) && ws_bytes >= iap_smo_image_ws_bytes(n, Y, X, sigma), IAP_E_WS,
+                "iap_smo_image: sigma > 0 needs a 16-byte aligned workspace of %zu bytes (got %zu)",
+                iap_smo_image_ws_bytes(n, Y, X, sigma), ws_bytes);
+    float* ftmp = (float*)ws;
+    float* fsm = ftmp + (size_t)n * Y * X;
+    rc = in_kind == 0 ? launch_gauss_reflect<uint16_t>((const uint16_t*)in, ftmp, fsm, n, Y, X, sigma, st)
+                      : launch_gauss_reflect<float>((const float*)in, ftmp, fsm, n, Y, X, sigma, st);
+    if (rc) return rc;
+    return launch_smo<float, SMO_MODE_IMAGE>(fsm, nullptr, out, nullptr, n, Y, X, size, 0.f, st);
+  }
   if (in_kind == 0)
     return launch_smo<uint16_t, SMO_MODE_IMAGE>((const uint16_t*)in, nullptr, out, nullptr, n, Y, X, size, 0.f,
                                                 st);
@@ -765,12 +780,12 @@ static int64_t bg_batch_planes(int64_t n, int Y, int X) {
   return b;
 }
 
-extern "C" size_t iap_bg_smo_ws_bytes(int64_t n, int Y, int X) {
+extern "C" size_t iap_bg_smo_ws_bytes(int64_t n, int Y, int X, float sigma) {
   if (n <= 0 || Y <= 0 || X <= 0) return 0;
   int64_t b = bg_batch_planes(n, Y, X);
-  // per batch plane: histogram words + med2 + nbg ; plus two float planes for sigma > 0
-  size_t per = (size_t)HIST_WORDS * 4 + 16 + (size_t)Y * X * 8;
-  return (size_t)b * per + 256;
+  // per batch plane: histogram words + med2 + nbg; with sigma > 0 two float planes on top (none at sigma = 0)
+  size_t per = (size_t)HIST_WORDS * 4 + 16 + (sigma > 0.f ? (size_t)Y * X * 8 : 0);
+  return (size_t)b * per + 512;
 }
 
 extern "C" int iap_bg_smo_u16(const uint16_t* in, uint16_t* out, int64_t n, int Y, int X, float sigma, int size,
@@ -784,8 +799,8 @@ extern "C" int iap_bg_smo_u16(const uint16_t* in, uint16_t* out, int64_t n, int 
   IAP_REQUIRE(size & 1, IAP_E_ARG, "iap_bg_smo_u16: size must be odd");
   IAP_REQUIRE(sigma >= 0.f, IAP_E_ARG, "iap_bg_smo_u16: sigma must be >= 0");
   IAP_REQUIRE(ws && aligned16(ws), IAP_E_ARG, "iap_bg_smo_u16: workspace missing or not 16-byte aligned");
-  IAP_REQUIRE(ws_bytes >= iap_bg_smo_ws_bytes(n, Y, X), IAP_E_WS,
-              "iap_bg_smo_u16: workspace of %zu bytes, need %zu", ws_bytes, iap_bg_smo_ws_bytes(n, Y, X));
+  IAP_REQUIRE(ws_bytes >= iap_bg_smo_ws_bytes(n, Y, X, sigma), IAP_E_WS,
+              "iap_bg_smo_u16: workspace of %zu bytes, need %zu", ws_bytes, iap_bg_smo_ws_bytes(n, Y, X, sigma));
   hipStream_t st = as_stream(stream);
   int64_t B = bg_batch_planes(n, Y, X);
   if (sigma == 0.f && !out) {
@@ -872,6 +887,12 @@ extern "C" int iap_gauss_blur_u16(const uint16_t* in, uint16_t* out, int64_t n, 
   // taps as cv2.getGaussianKernel(k, sigma, CV_32F); they ride to the kernel by value
   GaussTaps h;
   auto fill = [](int k, float sg, float* t) {
+    if (!(sg > 0) && k <= 7) {   // OpenCV's fixed table for small kernels without a sigma (small_gaussian_tab)
+      static const float tab[4][4] = {{1.f, 0.f, 0.f, 0.f}, {0.5f, 0.25f, 0.f, 0.f}, {0.375f, 0.25f, 0.0625f, 0.f},
+                                      {0.28125f, 0.21875f, 0.109375f, 0.03125f}};
+      for (int i = 0; i <= (k - 1) / 2; ++i) t[i] = tab[(k - 1) / 2][i];
+      return;
+    }
     double s = sg > 0 ? sg : 0.3 * ((k - 1) * 0.5 - 1) + 0.8;
     double w[2 * GB_MAXR + 1], sum = 0;
     for (int i = 0; i < k; ++i) {
@@ -887,6 +908,9 @@ extern "C" int iap_gauss_blur_u16(const uint16_t* in, uint16_t* out, int64_t n, 
   int rx = (kx - 1) / 2, ry = (ky - 1) / 2;
   size_t lds = ((size_t)(GB_TY + 2 * ry) * (GB_TX + 2 * rx) + (size_t)(GB_TY + 2 * ry) * GB_TX + rx + ry + 2) * 4;
   dim3 grid((X + GB_TX - 1) / GB_TX, (Y + GB_TY - 1) / GB_TY, (unsigned)n);
+  if (lds > 48 * 1024)   // kernels of 57 and up pass the default 64 KB of dynamic LDS (71 KB at 63): ask for it
+    IAP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_blur_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   { ProfScope ps_(K_GAUSS, st); hipLaunchKernelGGL(gauss_blur_kernel, grid, dim3(256), lds, st, in, out, Y, X, rx, ry, h); }
   IAP_LAUNCH_CHECK();
   return IAP_OK;

@@ -887,7 +887,8 @@ __global__ __launch_bounds__(256) void mip_kernel(const uint16_t* __restrict__ i
   const long long item = blockIdx.y;
   const uint16_t* p = in + item * in_stride;
   uint16_t* o = out + item * px;
-  const long long nv = px >> 3;
+  // 16-byte accesses need every plane z * px of the item to start aligned: px % 8 == 0; else all scalar
+  const long long nv = (px & 7) ? 0 : (px >> 3);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv;
        i += (long long)gridDim.x * blockDim.x) {
     u16x8 m;
@@ -901,13 +902,11 @@ __global__ __launch_bounds__(256) void mip_kernel(const uint16_t* __restrict__ i
     }
     store8(o + i * 8, m);
   }
-  if (blockIdx.x == 0) {
-    long long i = nv * 8 + threadIdx.x;
-    if (i < px) {
-      int m = 0;
-      for (int z = 0; z < Z; ++z) m = max(m, (int)p[z * px + i] - plane_level(sub2, item * sub_stride + z));
-      o[i] = (uint16_t)m;
-    }
+  for (long long i = nv * 8 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < px;
+       i += (long long)gridDim.x * blockDim.x) {   // scalar: nothing when px % 8 == 0, the whole plane otherwise
+    int m = 0;
+    for (int z = 0; z < Z; ++z) m = max(m, (int)p[z * px + i] - plane_level(sub2, item * sub_stride + z));
+    o[i] = (uint16_t)m;
   }
 }
 
@@ -1613,8 +1612,10 @@ extern "C" int iap_mip_u16(const uint16_t* in, int64_t in_stride, uint16_t* out,
   IAP_REQUIRE(n > 0 && Z > 0 && Y > 0 && X > 0, IAP_E_ARG, "iap_mip_u16: non-positive size");
   long long px = (long long)Y * X;
   IAP_REQUIRE(in_stride >= (int64_t)Z * px, IAP_E_ARG, "iap_mip_u16: in_stride smaller than one item");
-  IAP_REQUIRE(aligned16(in) && aligned16(out) && (px % 8 == 0 || n == 1) && in_stride % 8 == 0, IAP_E_ALIGN,
-              "iap_mip_u16: pointers must be 16-byte aligned and Y*X, in_stride multiples of 8");
+  // planes of a multiple of 8 pixels go through 16-byte accesses (every plane of every item must then start on a
+  // 16-byte boundary); any other plane size takes the kernel's scalar path and needs no alignment at all
+  IAP_REQUIRE(px % 8 != 0 || (aligned16(in) && aligned16(out) && (in_stride % 8 == 0 || n == 1)), IAP_E_ALIGN,
+              "iap_mip_u16: with Y*X a multiple of 8, pointers must be 16-byte aligned and in_stride a multiple of 8");
   return launch_mip(in, in_stride, out, n, Z, px, as_stream(stream));
 }
 
@@ -1624,8 +1625,10 @@ extern "C" int iap_mip_sub_u16(const uint16_t* in, int64_t in_stride, uint16_t* 
   IAP_REQUIRE(n > 0 && Z > 0 && Y > 0 && X > 0, IAP_E_ARG, "iap_mip_sub_u16: non-positive size");
   long long px = (long long)Y * X;
   IAP_REQUIRE(in_stride >= (int64_t)Z * px && sub_stride >= Z, IAP_E_ARG, "iap_mip_sub_u16: stride smaller than one item");
-  IAP_REQUIRE(aligned16(in) && aligned16(out) && (px % 8 == 0 || n == 1) && in_stride % 8 == 0, IAP_E_ALIGN,
-              "iap_mip_sub_u16: pointers must be 16-byte aligned and Y*X, in_stride multiples of 8");
+  // planes of a multiple of 8 pixels go through 16-byte accesses (every plane of every item must then start on a
+  // 16-byte boundary); any other plane size takes the kernel's scalar path and needs no alignment at all
+  IAP_REQUIRE(px % 8 != 0 || (aligned16(in) && aligned16(out) && (in_stride % 8 == 0 || n == 1)), IAP_E_ALIGN,
+              "iap_mip_sub_u16: with Y*X a multiple of 8, pointers must be 16-byte aligned and in_stride a multiple of 8");
   PlaneSub s;
   s.sub2 = (const int*)sub2;
   s.stride = sub_stride;

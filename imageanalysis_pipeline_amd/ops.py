@@ -137,8 +137,9 @@ def _planes(t: torch.Tensor):
     return n, y, x
 
 
-def smo_image(planes: torch.Tensor, size: int = 7) -> torch.Tensor:
-    """SMO value (float32) of u16 or f32 planes (..., Y, X)  [smo.SMO.smo_image, utility.py:252]."""
+def smo_image(planes: torch.Tensor, size: int = 7, sigma: float = 0.0) -> torch.Tensor:
+    """SMO value (float32) of u16 or f32 planes (..., Y, X)  [smo.SMO.smo_image, utility.py:252]; ``sigma`` > 0:
+    gaussian pre-smoothing first, as ``SMO(sigma=...)``."""
     _need_cuda(planes)
     if planes.dtype == torch.uint16:
         kind = 0
@@ -149,8 +150,11 @@ def smo_image(planes: torch.Tensor, size: int = 7) -> torch.Tensor:
     n, y, x = _planes(planes)
     out = torch.empty(planes.shape, dtype=torch.float32, device=planes.device)
     lib = _lib.load()
-    _lib.check(lib.iap_smo_image(planes.data_ptr(), kind, out.data_ptr(), n, y, x, 0.0, int(size), _stream()),
-               "iap_smo_image")
+    nb = lib.iap_smo_image_ws_bytes(n, y, x, float(sigma))
+    ws = _workspace(nb, planes.device) if nb else None
+    _lib.check(lib.iap_smo_image(planes.data_ptr(), kind, out.data_ptr(), n, y, x, float(sigma), int(size),
+                                 ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0,
+                                 _stream()), "iap_smo_image")
     return out
 
 
@@ -159,15 +163,14 @@ _thr_cache: dict = {}
 
 def smo_threshold(shape, sigma: float = 0.0, size: int = 7, seed: int = 0, q: float = 0.05, device="cuda") -> float:
     """5 % quantile of the SMO value of a seeded normal-noise image (the null distribution the
-    reference draws unseeded in ``SMO(shape=...)``, utility.py:252).  The SMO image comes from
-    the HIP kernel; only the quantile selection of the copied-back values runs on the host."""
-    if sigma and sigma > 0:
-        raise NotImplementedError("null threshold with sigma > 0: pass an explicit threshold")
+    reference draws unseeded in ``SMO(shape=..., sigma=, size=)``, utility.py:252: the same operator, gaussian
+    pre-smoothing included, applied to the noise image).  The SMO image comes from the HIP kernels; only the
+    quantile selection of the copied-back values runs on the host."""
     key = (tuple(shape), float(sigma), int(size), int(seed), float(q))
     if key not in _thr_cache:
         rng = np.random.default_rng(seed)
         null = torch.from_numpy(rng.standard_normal(size=tuple(shape)).astype(np.float32)).to(device)
-        s = smo_image(null, size).cpu().numpy().astype(np.float64)
+        s = smo_image(null, size, sigma).cpu().numpy().astype(np.float64)
         _thr_cache[key] = float(np.quantile(s, q))
     return _thr_cache[key]
 
@@ -185,7 +188,7 @@ def bg_smo(planes: torch.Tensor, threshold: float, sigma: float = 0.0, size: int
     if out.shape != planes.shape:
         raise ValueError("out must have the shape of planes")
     lib = _lib.load()
-    nb = lib.iap_bg_smo_ws_bytes(n, y, x)
+    nb = lib.iap_bg_smo_ws_bytes(n, y, x, float(sigma))
     ws = _workspace(nb, planes.device)
     med2 = torch.empty(n, dtype=torch.int32, device=planes.device)
     nbg = torch.empty(n, dtype=torch.int32, device=planes.device)
@@ -202,7 +205,7 @@ def bg_smo_levels(planes: torch.Tensor, threshold: float, sigma: float = 0.0, si
     _u16(planes)
     n, y, x = _planes(planes)
     lib = _lib.load()
-    ws = _workspace(lib.iap_bg_smo_ws_bytes(n, y, x), planes.device)
+    ws = _workspace(lib.iap_bg_smo_ws_bytes(n, y, x, float(sigma)), planes.device)
     med2 = torch.empty(n, dtype=torch.int32, device=planes.device)
     nbg = torch.empty(n, dtype=torch.int32, device=planes.device)
     _lib.check(lib.iap_bg_smo_u16(planes.data_ptr(), None, n, y, x, float(sigma), int(size), float(threshold),

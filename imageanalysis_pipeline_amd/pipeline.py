@@ -66,18 +66,25 @@ class Utility:
     @staticmethod
     def _folder_index(fold_path):
         """{(prefix, frame, z): filename} built with ONE listdir (the reference re-lists and re-sorts
-        the folder for every (channel, frame): utility.py:513-517)."""
+        the folder for every (channel, frame): utility.py:513-517).  Two name forms exist in the reference:
+        ``<prefix>_fNNNN_zNNNN.tif`` (create_imseq / save_mask, utility.py:158-166, 612-618) and
+        ``<prefix>_fNNNN.tif`` without a z token (the reference masks of ref_mask, utility.py:859, 866, which
+        its own load_mask finds through the digit count of the last token, utility.py:588-594): z = 0 there."""
         idx = {}
         for im in sorted(listdir(fold_path)):
             if not im.endswith(".tif"):
                 continue
             parts = im[:-4].split("_")
             try:
-                z = int(parts[-1][1:])
-                f = int(parts[-2][1:])
+                if parts[-1][:1] == "z" and len(parts) >= 3 and parts[-2][:1] == "f":
+                    z, f, npre = int(parts[-1][1:]), int(parts[-2][1:]), len(parts) - 2
+                elif parts[-1][:1] == "f" and len(parts) >= 2:
+                    z, f, npre = 1, int(parts[-1][1:]), len(parts) - 1
+                else:
+                    continue
             except (ValueError, IndexError):
                 continue
-            idx[("_".join(parts[:-2]), f - 1, z - 1)] = im
+            idx[("_".join(parts[:npre]), f - 1, z - 1)] = im
         return idx
 
     @staticmethod
@@ -517,6 +524,12 @@ class Analysis(Utility):
             else:
                 mask_keys = [chan for chan in self.channel_list]
             keys = ["cell", "frames", "time", "mask_chan", "tag", "exp"] + mask_keys
+            is_class = maskFold == "Masks_Class"
+            if is_class:                                                      # analysis.py:46-50, 63
+                class_keys = self.exp_prop["channel_seg"]["Masks_Class"]
+                pos_lst = self.exp_prop["masks_process"]["classification"]["pos"]
+                neg_lst = self.exp_prop["masks_process"]["classification"]["neg"]
+                keys += ["cell_class", "pos_cell"]
             exp_name = self._exp_name()
             img_stack = Utility._read_folder_stack(join(sep, self.exp_path + sep, imgFold), self.exp_prop["metadata"])
             df = pd.DataFrame()
@@ -536,6 +549,12 @@ class Analysis(Utility):
                             d["exp"].append(exp_name)
                             d["frames"].append(f + 1)
                             d["time"].append(t)
+                            if is_class:                                      # analysis.py:87-92, as written there:
+                                d["cell_class"].append(f"if cell is {class_keys[1]}")
+                                if obj in pos_lst:                            # an object in neither list gets no entry
+                                    d["pos_cell"].append(1)
+                                elif obj in neg_lst:
+                                    d["pos_cell"].append(0)
                             for ci, ch in enumerate(self.channel_list):
                                 for name in mask_keys:
                                     if ch in name:                       # analysis.py:96-98, incl. its substring match

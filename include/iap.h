@@ -39,12 +39,16 @@ const char* iap_last_error(void);
 
 /* SMO operator value per pixel (float32) of n planes.  in_kind: 0 = u16 planes, 1 = f32 planes.
  * Replaces smo.SMO.smo_image as used by utility.py:252,260 (null-distribution threshold and
- * tests).  sigma > 0 adds the gaussian pre-smoothing (scipy 'reflect', truncate 4). */
+ * tests).  sigma > 0 adds the gaussian pre-smoothing (scipy 'reflect', truncate 4) that SMO(sigma=...)
+ * applies (utility.py:242, 252; kwarg plumbed from core.py:76) and needs a workspace of
+ * iap_smo_image_ws_bytes (0 at sigma == 0: ws may then be NULL). */
+size_t iap_smo_image_ws_bytes(int64_t n, int Y, int X, float sigma);
 int iap_smo_image(const void* in, int in_kind, float* out, int64_t n, int Y, int X,
-                  float sigma, int size, void* stream);
+                  float sigma, int size, void* ws, size_t ws_bytes, void* stream);
 
-/* Workspace bytes for iap_bg_smo_u16 on n planes. */
-size_t iap_bg_smo_ws_bytes(int64_t n, int Y, int X);
+/* Workspace bytes for iap_bg_smo_u16 on n planes with the given sigma (the two float planes per batch
+ * plane are only needed for sigma > 0). */
+size_t iap_bg_smo_ws_bytes(int64_t n, int Y, int X, float sigma);
 
 /* utility.py:255-264 smo_bg_sub hot loop, for n independent u16 planes:
  *   mask = SMO(plane) < threshold ; med = median(plane[mask]) ;

@@ -160,8 +160,20 @@ def bg_manual(img: np.ndarray, r0: int, c0: int, r1: int, c1: int) -> tuple[np.n
 # --------------------------------------------------------------------------------------
 
 
+_CV_SMALL_GAUSS = {
+    1: [1.0],
+    3: [0.25, 0.5, 0.25],
+    5: [0.0625, 0.25, 0.375, 0.25, 0.0625],
+    7: [0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125],
+}
+
+
 def gauss_taps_cv(ksize: int, sigma: float) -> np.ndarray:
-    """cv2.getGaussianKernel(ksize, sigma, CV_32F): sigma<=0 -> 0.3*((k-1)*0.5-1)+0.8."""
+    """cv2.getGaussianKernel(ksize, sigma, CV_32F): sigma<=0 -> 0.3*((k-1)*0.5-1)+0.8, except that OpenCV
+    takes odd sizes up to 7 with sigma <= 0 from a fixed table (its small_gaussian_tab: binomial-like
+    weights, e.g. 0.25 / 0.5 / 0.25 for 3 taps), not from the exponential."""
+    if sigma <= 0 and ksize in _CV_SMALL_GAUSS:
+        return np.asarray(_CV_SMALL_GAUSS[ksize], dtype=np.float32)
     if sigma <= 0:
         sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8
     x = np.arange(ksize, dtype=np.float64) - (ksize - 1) * 0.5

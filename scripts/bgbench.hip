@@ -16,7 +16,7 @@ int main(int argc, char** argv) {
   uint16_t *in, *out; void* ws; int *med2, *nbg;
   size_t px = (size_t)n * Y * X;
   hipMalloc(&in, px * 2); hipMalloc(&out, px * 2); hipMalloc(&med2, n * 4); hipMalloc(&nbg, n * 4);
-  size_t wsb = iap_bg_smo_ws_bytes(n, Y, X); hipMalloc(&ws, wsb);
+  size_t wsb = iap_bg_smo_ws_bytes(n, Y, X, 0.f); hipMalloc(&ws, wsb);
   fill<<<4096, 256>>>(in, px);
   hipDeviceSynchronize();
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);

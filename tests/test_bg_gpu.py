@@ -165,7 +165,8 @@ def test_bg_manual(dev):
         ops.bg_manual(ops.to_device_u16(tie, dev), (0, 0, 9, 1))
 
 
-@pytest.mark.parametrize("k,sig", [((15, 15), 5.0), ((3, 7), 0.0), ((31, 5), 2.5)])
+@pytest.mark.parametrize("k,sig", [((15, 15), 5.0), ((3, 7), 0.0), ((31, 5), 2.5), ((63, 63), 12.0), ((57, 61), 0.0),
+                                   ((5, 1), 0.0)])
 def test_gauss_blur_bit_exact(dev, k, sig):
     from imageanalysis_pipeline_amd import ops
     rng = np.random.default_rng(12)
@@ -175,3 +176,19 @@ def test_gauss_blur_bit_exact(dev, k, sig):
         assert np.array_equal(got[i], O.gauss_blur(img[i], k, sig))
     with pytest.raises(TypeError):
         ops.gauss_blur(ops.to_device_u16(img, dev), [15, 15], 5.0)
+
+
+def test_smo_image_and_threshold_with_sigma(dev):
+    """SMO(sigma > 0): gaussian pre-smoothing (scipy 'reflect', truncate 4) ahead of the operator, for the
+    image planes and for the null image the threshold comes from (utility.py:252)."""
+    from imageanalysis_pipeline_amd import ops
+    img = _frames(2, 128, 256, seed=13)
+    got = ops.smo_image(ops.to_device_u16(img, dev), 7, sigma=1.5).cpu().numpy()
+    for i in range(2):
+        # the smoothed plane is kept in fp32: ~500 counts +- 3e-5, and the operator takes differences of
+        # neighbours that differ by a count or so -> 1e-4 on the SMO value (2e-6 without the pre-filter)
+        assert np.abs(got[i] - O.smo_image(img[i].astype(np.float64), 1.5, 7)).max() <= 3e-4
+    t = ops.smo_threshold((128, 256), sigma=1.5, seed=0, device=dev)
+    e = O.smo_threshold((128, 256), sigma=1.5, seed=0)
+    assert abs(t - e) <= 2e-5 * e + 2e-6
+    assert t != ops.smo_threshold((128, 256), sigma=0.0, seed=0, device=dev)

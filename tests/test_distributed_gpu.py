@@ -1,0 +1,121 @@
+"""GPU: the multi-GPU drivers of distributed.py (FOV sharding, core.py:99-112 / 327-337 loops; time blocks) run
+on the card.  Single rank against the sequential ops path and the oracle on a C4-shaped (3-channel) plate, then two
+ranks (gloo, both on this box's GPU) against the single-process result: the gathered table must be identical."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ref_path as O
+from imageanalysis_pipeline_amd import distributed as D
+from imageanalysis_pipeline_amd import ops, synth
+
+pytestmark = pytest.mark.gpu
+
+T, C, Y, X, NFOV, CELLS = 4, 3, 128, 256, 3, 8      # BASELINE configs[3] in small: a plate of 3-channel FOVs
+
+
+def _fov(i, dev):
+    st, _ = synth.make_stack(T, C, 1, Y, X, n_cells=CELLS, integer_drift=True, seed=20 + i)
+    lab = np.stack([synth.make_labels(Y, X, CELLS, seed=20 + i)[None]] * T)
+    return st, lab, ops.to_device_u16(st, dev), ops.to_device_u16(lab, dev)
+
+
+def _sequential_rows(dev, thr, reg_ref, fovs):
+    parts = []
+    for i in fovs:
+        _, _, st, lab = _fov(i, dev)
+        bg, _, _ = ops.bg_smo(st, thr)
+        reg, _ = ops.im_reg(bg, 0, reg_ref)
+        parts.append(D.pack_rows(ops.measure_finalize(ops.measure_accumulate(reg, lab)), i))
+    return torch.cat(parts, 0)
+
+
+@pytest.mark.parametrize("reg_ref", ["mean", "first"])
+def test_process_plate_single_rank_c4_shaped(dev, reg_ref):
+    thr = O.smo_threshold((Y, X))
+    rows = D.process_plate(lambda i: _fov(i, dev)[2:], NFOV, thr, reg_ref=reg_ref)
+    ref = _sequential_rows(dev, thr, reg_ref, range(NFOV))
+    assert rows.shape == ref.shape == (rows.shape[0], 4 + C + 3)
+    assert torch.equal(rows, ref)                        # subtract-on-load == two passes, bit for bit
+    # and against the oracle, FOV by FOV: ids and areas exact, centroids exact, means within 1e-4 relative
+    # (each side warps with its own sub-pixel shifts, tests/test_path_gpu.py)
+    rows = rows.cpu().numpy()
+    for i in range(NFOV):
+        st, lab, _, _ = _fov(i, dev)
+        _, _, etab = O.run_path_opts(st, lab, thr, reg_ref=reg_ref, upsample=True)
+        mine = rows[rows[:, 0] == i]
+        pos = 0
+        for f, e in enumerate(etab):
+            part = mine[mine[:, 1] == f]
+            assert np.array_equal(part[:, 2].astype(np.int64), e["ids"])
+            assert np.array_equal(part[:, 3].astype(np.int64), e["area"])
+            assert np.array_equal(np.rint(part[:, 4 + C + 1:]).astype(np.int64), e["centroid_rne"])
+            assert (np.abs(part[:, 4:4 + C] - e["mean"]) <= 1e-4 * np.abs(e["mean"])).all()
+            pos += len(part)
+        assert pos == len(mine)
+
+
+@pytest.mark.parametrize("reg_ref", ["mean", "first"])
+def test_process_fov_timeblocks_single_rank(dev, reg_ref):
+    thr = O.smo_threshold((Y, X))
+    _, _, st, lab = _fov(1, dev)
+    rows, shifts = D.process_fov_timeblocks(lambda t0, t1: (st[t0:t1].contiguous(), lab[t0:t1].contiguous()), T, thr,
+                                            reg_ref=reg_ref, fov=1)
+    bg, _, _ = ops.bg_smo(st, thr)
+    reg, sh = ops.im_reg(bg, 0, reg_ref)
+    ref = D.pack_rows(ops.measure_finalize(ops.measure_accumulate(reg, lab)), 1)
+    assert torch.equal(shifts, sh) and torch.equal(rows, ref)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # gloo: both ranks sit on the one GPU here
+    try:
+        dev = torch.device("cuda", rank % torch.cuda.device_count())
+        torch.cuda.set_device(dev)
+        thr = O.smo_threshold((Y, X))
+        plate = D.process_plate(lambda i: _fov(i, dev)[2:], 5, thr, reg_ref="mean")
+        _, _, st, lab = _fov(0, dev)
+        tb_rows, tb_sh = D.process_fov_timeblocks(lambda t0, t1: (st[t0:t1].contiguous(), lab[t0:t1].contiguous()), T,
+                                                  thr, reg_ref="mean", fov=0)
+        q.put((rank, plate.cpu().numpy(), tb_rows.cpu().numpy(), tb_sh.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_process(dev):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=170) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    thr = O.smo_threshold((Y, X))
+    ref = _sequential_rows(dev, thr, "mean", range(5)).cpu().numpy()
+    _, _, st, lab = _fov(0, dev)
+    bg, _, _ = ops.bg_smo(st, thr)
+    reg, sh = ops.im_reg(bg, 0, "mean")
+    tb_ref = D.pack_rows(ops.measure_finalize(ops.measure_accumulate(reg, lab)), 0).cpu().numpy()
+    sh = sh.cpu().numpy()
+    for rank, plate, tb_rows, tb_sh in res:
+        assert np.array_equal(plate, ref)                    # rank order == FOV order, identical on every rank
+        assert np.array_equal(tb_rows, tb_ref)               # time blocks: the rows of a single-process run
+        fr = D.shard_frames(T, rank, world)
+        assert np.array_equal(tb_sh, sh[fr.start:fr.stop])

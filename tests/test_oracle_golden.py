@@ -119,3 +119,17 @@ def test_label_morphology_vs_scipy():
         assert np.array_equal(O.label_dilate(lab, r), g[f"dilate_{r}"])
     # iterations = repeated application (cv2 iterations=)
     assert np.array_equal(O.label_erode(lab, 2, iterations=2), O.label_erode(O.label_erode(lab, 2), 2))
+
+
+def test_gauss_taps_cv_small_kernel_tables():
+    """cv2.getGaussianKernel: odd sizes up to 7 with sigma <= 0 come from OpenCV's fixed table, everything
+    else from the normalised exponential (sigma <= 0 -> 0.3*((k-1)*0.5-1)+0.8)."""
+    assert np.array_equal(O.gauss_taps_cv(3, 0.0), np.float32([0.25, 0.5, 0.25]))
+    assert np.array_equal(O.gauss_taps_cv(5, -1.0), np.float32([0.0625, 0.25, 0.375, 0.25, 0.0625]))
+    assert np.array_equal(O.gauss_taps_cv(7, 0.0), np.float32([0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125]))
+    assert np.array_equal(O.gauss_taps_cv(1, 0.0), np.float32([1.0]))
+    w = O.gauss_taps_cv(9, 0.0)                       # no table: sigma = 0.3*(4-1)+0.8 = 1.7
+    x = np.arange(9) - 4.0
+    e = np.exp(-x * x / (2 * 1.7 * 1.7))
+    assert np.allclose(w, e / e.sum(), rtol=1e-6) and abs(float(w.sum()) - 1.0) < 1e-6
+    assert not np.array_equal(O.gauss_taps_cv(3, 0.8), O.gauss_taps_cv(3, 0.0))   # an explicit sigma is honoured

@@ -24,6 +24,10 @@ def test_mip(dev):
     a = rng.integers(0, 65536, size=(3, 5, 40, 64)).astype(np.uint16)
     got = ops.to_numpy_u16(ops.mip(ops.to_device_u16(a, dev)))
     assert np.array_equal(got, a.max(axis=1))
+    # one item whose planes are not a multiple of 8 pixels: every plane but the first starts off a 16-byte
+    # boundary, so the kernel must take its scalar path (no misaligned vector loads)
+    b = rng.integers(0, 65536, size=(1, 4, 37, 51)).astype(np.uint16)
+    assert np.array_equal(ops.to_numpy_u16(ops.mip(ops.to_device_u16(b, dev))), b.max(axis=1))
 
 
 @pytest.mark.parametrize("shape", [(64, 64), (128, 256), (256, 128), (512, 512), (100, 300), (1024, 64), (4096, 64), (64, 4096)])

@@ -69,6 +69,32 @@ def test_save_and_load_mask(tmp_path):
         Utility.load_mask(mdir, "GFP", input_range=2)                # utility.py:568-569
 
 
+def test_load_mask_reference_names_without_z_token(tmp_path):
+    """The reference writes its wound / reference masks as mask_<label>_fNNNN.tif, no _z token
+    (utility.py:859, 866), and its own load_mask finds them (utility.py:586-594)."""
+    exp, _ = make_exp(tmp_path, t=3)
+    mdir = os.path.join(exp, "Masks_wound")
+    os.makedirs(mdir)
+    masks = np.random.default_rng(3).integers(0, 2, size=(3, 16, 24)).astype(np.uint16)
+    for f in range(3):
+        tiffio.imwrite(os.path.join(mdir, "mask_wound_f%04d.tif" % (f + 1)), masks[f])
+    assert np.array_equal(Utility.load_mask(mdir, "wound", do_log=False), masks)
+    assert np.array_equal(Utility.load_mask(mdir, "wound", input_range=[1], do_log=False), masks[1])
+    # ref_mask's loading branch (utility.py:849-852) goes through the same reader
+    assert np.array_equal(Utility.ref_mask(os.path.join(exp, "Images"), "wound"), masks)
+    # the single-frame form: one file, mask_<label>_f0001.tif (utility.py:859)
+    exp1, _ = make_exp(tmp_path / "one", t=1)
+    m1 = os.path.join(exp1, "Masks_wound")
+    os.makedirs(m1)
+    tiffio.imwrite(os.path.join(m1, "mask_wound_f0001.tif"), masks[0])
+    assert np.array_equal(Utility.load_mask(m1, "wound", do_log=False), masks[0])
+    # three-digit frame numbers (the reference reads either width, utility.py:587-588)
+    idx = Utility._folder_index(mdir)
+    assert ("mask_wound", 0, 0) in idx and len(idx) == 3
+    tiffio.imwrite(os.path.join(mdir, "mask_other_f004.tif"), masks[0])
+    assert Utility._folder_index(mdir)[("mask_other", 3, 0)] == "mask_other_f004.tif"
+
+
 def test_error_conventions_without_gpu(tmp_path):
     exp, _ = make_exp(tmp_path)
     img = os.path.join(exp, "Images")

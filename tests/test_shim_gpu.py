@@ -53,7 +53,10 @@ def test_pre_process_and_analysis_sequence(dev, tmp_path):
     for f in range(t):
         for ci, ch in enumerate(chans):
             reg[f, ci, 0] = tiffio.imread(os.path.join(regdir, "%s_f%04d_z0001.tif" % (ch, f + 1)))
-    assert np.abs(reg.astype(np.int64) - ereg.astype(np.int64)).max() <= 2
+    # the shim refines to sub-pixel shifts (upsample), so the warp interpolates even on integer drift.  Bar: 1 count
+    # (float error of the fp32 warp + the shift difference times the local gradient stays
+    # below one count, and truncating two values less than 1 apart gives integers at most 1 apart)
+    assert np.abs(reg.astype(np.int64) - ereg.astype(np.int64)).max() <= 1
     # second call without reg_ow: skipped (utility.py:292), files untouched
     mt = os.path.getmtime(os.path.join(regdir, "GFP_f0001_z0001.tif"))
     Utility.im_reg(img, "GFP", "translation", False, "first", False)
@@ -122,10 +125,12 @@ def test_pixel_distance_table(dev, tmp_path):
     for f in range(t):
         wound[f, 30:50 - 3 * f, 40 + 5 * f:90] = 1                    # a closing wound
     cells = np.stack([synth.make_labels(y, x, 8, seed=f) for f in range(t)])
-    for name, arr, key in (("Masks_wound", wound, "wound"), ("Masks_CP", cells, "GFP")):
-        d = os.path.join(exp, name)
-        os.makedirs(d)
-        Utility.save_mask(arr, d, batch=list(range(t)), z_size=1, frames=t, chan_seg=key)
+    # the reference masks under the names the reference itself gives them (utility.py:866: no _z token)
+    os.makedirs(os.path.join(exp, "Masks_wound"))
+    for f in range(t):
+        tiffio.imwrite(os.path.join(exp, "Masks_wound", "mask_wound_f%04d.tif" % (f + 1)), wound[f])
+    os.makedirs(os.path.join(exp, "Masks_CP"))
+    Utility.save_mask(cells, os.path.join(exp, "Masks_CP"), batch=list(range(t)), z_size=1, frames=t, chan_seg="GFP")
 
     a = Analysis(exp, "GFP")
     a.pixel_distance(imgFold="Images", maskFold="Masks_CP", maskLabel="wound")
@@ -145,3 +150,56 @@ def test_pixel_distance_table(dev, tmp_path):
     # apply_dmap keeps the reference's return shapes
     assert Utility.apply_dmap(wound[0], 1).shape == (y, x)
     assert np.array_equal(Utility.apply_dmap(wound, t)[1], np.sqrt(O.edt_sq(wound[1]).astype(float)))
+
+
+def test_masks_class_columns(dev, tmp_path):
+    """extract_channelData(maskFold='Masks_Class') adds the reference's cell_class / pos_cell columns
+    (analysis.py:44-52, 63, 87-92)."""
+    t, c, y, x = 2, 2, 64, 96
+    chans = ("GFP", "RFP")
+    exp, stack = make_exp(tmp_path, t=t, c=c, y=y, x=x, chans=chans)
+    lab = synth.make_labels(y, x, 6, seed=3)
+    ids = [int(v) for v in np.unique(lab)[1:]]
+    cdir = os.path.join(exp, "Masks_CP")
+    os.makedirs(cdir)
+    Utility.save_mask(np.stack([lab] * t), cdir, batch=list(range(t)), z_size=1, frames=t, chan_seg="GFP")
+    prop = Utility.open_exp_prop(exp)
+    prop["channel_seg"] = {"Masks_Class": ["GFP", "RFP"]}
+    prop["masks_process"]["classification"] = {"folder": "Masks_CP", "pos": ids[::2], "neg": ids[1::2]}
+    Utility.save_exp_prop(exp, prop)
+    a = Analysis(exp, "GFP")
+    a.extract_channelData(imgFold="Images", maskFold="Masks_Class")
+    df = a.df_analysis
+    assert list(df.columns) == ["cell", "frames", "time", "mask_chan", "tag", "exp", "GFP", "RFP", "cell_class", "pos_cell"]
+    assert (df["cell_class"] == "if cell is RFP").all()
+    assert len(df) == t * len(ids)
+    for _, d in df.iterrows():
+        obj = int(d["cell"].rsplit("cell", 1)[1])
+        assert d["pos_cell"] == (1 if obj in ids[::2] else 0)
+        m = O.measure_labels_literal(stack[d["frames"] - 1, :, 0], lab)
+        i = list(m["ids"]).index(obj)
+        assert d["GFP"] == m["mean"][i, 0] and d["RFP"] == m["mean"][i, 1]
+
+
+def test_smo_bg_sub_with_sigma(dev, tmp_path):
+    """smo_bg_sub(sigma > 0) (utility.py:242, 252; kwarg from core.py:76): the null threshold and the planes go
+    through the same gaussian pre-filter.  Threshold within fp32 of the oracle's; with the oracle's threshold
+    the files equal the oracle's output."""
+    from imageanalysis_pipeline_amd import ops
+    t, c, y, x = 2, 1, 128, 256
+    exp, _ = make_exp(tmp_path, t=t, c=c, y=y, x=x, chans=("GFP",))
+    stack, _ = synth.make_stack(t, c, 1, y, x, n_cells=8, integer_drift=True, seed=9)
+    _write_stack(exp, stack, ("GFP",))
+    img = os.path.join(exp, "Images")
+    sigma = 1.5
+    thr = ops.smo_threshold((y, x), sigma=sigma, size=7, seed=0, device=dev)
+    ethr = O.smo_threshold((y, x), sigma=sigma, size=7, seed=0)
+    assert abs(thr - ethr) <= 2e-5 * ethr + 2e-6           # float32 noise image and filters vs float64
+    prop = Utility.smo_bg_sub(imgFold_path=img, sigma=sigma, size=7)
+    assert prop["fct_inputs"]["smo_bg_sub"]["smo_sigma"] == sigma
+    for f in range(t):
+        got = tiffio.imread(os.path.join(img, "GFP_f%04d_z0001.tif" % (f + 1)))
+        eout, emed2, enbg, emask = O.bg_smo(stack[f, 0, 0], thr, sigma=sigma)
+        # the mask may differ on pixels whose SMO value lies within the fp32 band of the threshold; the median
+        # of ~5 % of 32k pixels does not move with a handful of them on this input
+        assert np.array_equal(got, eout)
