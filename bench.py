@@ -1,28 +1,34 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mpx/s through background-subtract + register + per-label measure.
 
-One "step" = one pass of the whole hot path over one resident field of view:
-    iap_bg_smo_u16 (raw -> background level per plane)  ->  iap_im_reg_sub_u16 (raw - level -> registered)  ->
-    iap_measure_labels_u16 + iap_measure_finalize (registered + labels -> per-cell tables)
+One "step" = one pass of the whole hot path over one resident field of view (ops.hot_path):
+    iap_max_u16 (label range)  ->  iap_bg_smo_u16 (raw -> background level per plane)  ->
+    iap_im_reg_sub_u16 (raw - level -> registered)  ->  iap_measure_labels_u16 + iap_measure_finalize (tables)
 The background is subtracted as the registration kernels read the stack (same bits as writing the subtracted
-stack first; `--two-pass` runs that form: iap_bg_smo_u16 (raw -> bg) -> iap_im_reg_u16 (bg -> registered), and
-the default N=1 run reports its step time beside the headline as `two_pass_ms_per_step`).
-Workload at N=1: BASELINE.json configs[1] -- one FOV, 4 channels, 2048x2048 uint16, 500 frames
-with sub-pixel drift ("c2").  With --gpus N every rank holds its own FOV (weak scaling, FOV
-sharding, no data-path collective); the per-cell row tables are gathered to every rank with one
-RCCL all_gather inside the timed step.
+stack first; `--two-pass` runs that form, and the default N=1 run reports its step time as `two_pass_ms_per_step`).
+Workload at N=1: BASELINE.json configs[1] -- one FOV, 4 channels, 2048x2048 uint16, 500 frames with sub-pixel
+drift ("c2").  `--workload c1|c3|c5` run the other single-GPU configurations (c3 in time blocks: its registered
+copy does not fit beside the 104 GB stack).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` for the
-dominant kernel (HIP events round each of its launches in the timed steps, on the stream it is
-launched on, collected through iap_prof_*; one step profiled in full before the timed region
-names that kernel and fills the stage table) and `cpu_baseline` (the numpy oracle = restated
-reference CPU path, timed on this host on a bounded sample of the same workload).
+Multi-GPU: `--gpus N` with no torch.distributed environment makes this process -- which has not touched a GPU --
+start N ranks of itself with `python -m torch.distributed.run` and pass their line through; under the driver's own
+launcher (WORLD_SIZE set) it is one of the ranks.  Every rank holds its own FOV (weak scaling, FOV sharding, no
+data-path collective); the per-cell row tables are gathered to every rank with one RCCL all_gather inside the step.
+`n_gpus` is the world size RCCL actually formed.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` for the dominant kernel (HIP
+events round each of its launches in the timed steps, on the stream it is launched on, collected through
+iap_prof_*; `traffic` from two rocprofv3 --pmc passes run right after the timed steps over the same library through
+its native harness, scripts/pmc_traffic.py), `verified` (frames of the timed result checked against the oracle) and
+`cpu_baseline` (the numpy oracle = restated reference CPU path, timed on this host on a bounded sample).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,18 +38,18 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from imageanalysis_pipeline_amd import _lib, ops, synth  # noqa: E402
-
 HBM_PEAK = 8.0e12  # B/s, MI355X datasheet (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
 
 WORKLOADS = {
-    # name: (T, C, Z, Y, X, n_cells)
-    "c1": (100, 2, 1, 512, 512, 60),        # BASELINE configs[0]
-    "c2": (500, 4, 1, 2048, 2048, 300),     # BASELINE configs[1]  (metric config)
-    "c2small": (64, 4, 1, 2048, 2048, 300),
-    "c3": (24, 2, 31, 2048, 2048, 300),     # configs[2] shape, T reduced (full T=200 is 104 GB + outputs)
-    "c5": (16, 1, 1, 2048, 2048, 0),        # configs[4]: 5041 labels per frame
+    # name: (T, C, Z, Y, X, n_cells, tblock)
+    "c1": (100, 2, 1, 512, 512, 60, 0),        # BASELINE configs[0]
+    "c2": (500, 4, 1, 2048, 2048, 300, 0),     # BASELINE configs[1]  (metric config)
+    "c2small": (64, 4, 1, 2048, 2048, 300, 0),
+    "c3": (200, 2, 31, 2048, 2048, 300, 20),   # configs[2]: 104 GB stack, registered + measured 20 frames at a time
+    "c4fov": (300, 3, 1, 2048, 2048, 300, 0),  # one FOV of configs[3] (the plate is 64 of them, sharded over ranks)
+    "c5": (64, 1, 1, 2048, 2048, 0, 0),        # configs[4]: 5041 labels per frame
 }
+
 
 # algorithmic (compulsory) HBM bytes per stack pixel, SURVEY.md section 8(d)
 def stage_bytes_per_px(c: int, two_pass: bool = False) -> dict:
@@ -57,13 +63,30 @@ STAGE_OF_KERNEL = {
     "coarse_finish_kernel": "estimate", "upsample_partial_kernel": "estimate", "upsample_finish_kernel": "estimate",
     "mip_kernel": "estimate", "accum_planes_kernel": "estimate",
     "apply_shift_kernel": "apply", "measure_kernel": "measure", "measure_finalize_kernel": "measure",
+    "max_u16_kernel": "measure",
 }
+HARNESS_OF_STAGE = {"apply": lambda t, c, z, y, x: ["apply", t, c * z, y, x],
+                    "bg": lambda t, c, z, y, x: ["bg", t * c * z, y, x],
+                    "measure": lambda t, c, z, y, x: ["measure", t, c, y, x]}
 
 
-def make_device_stack(t, c, z, y, x, n_cells, device, seed=0, subpixel=True):
+def spawn_ranks(n: int) -> int:
+    """This process has made no GPU call: start n ranks of this script under torch's launcher (one process per
+    GPU, RCCL rendezvous on 127.0.0.1) and return their exit code.  Never an exec of a process that holds a GPU."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
+def make_device_stack(t, c, z, y, x, n_cells, device, seed=0, subpixel=True, label_frames=None):
     """Synthetic stack generated on the device (torch is only the data generator here): Poisson(100)+400
     background, Gaussian-blob cells, cumulative random-walk drift applied by Fourier shift before
     quantisation.  Returns (stack u16 (T,C,Z,Y,X), labels u16 (T,Z,Y,X), drift)."""
+    from imageanalysis_pipeline_amd import ops, synth
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     if n_cells > 0:
@@ -94,56 +117,36 @@ def make_device_stack(t, c, z, y, x, n_cells, device, seed=0, subpixel=True):
 class Path:
     """The hot path on one resident FOV."""
 
-    def __init__(self, stack, labels, reg_ref="mean", batch=64, two_pass=False):
+    def __init__(self, stack, labels, reg_ref="mean", batch=64, two_pass=False, tblock=0):
+        from imageanalysis_pipeline_amd import ops
+        self.ops = ops
         self.raw, self.labels = stack, labels
         self.bg = None
-        self.reg = torch.empty_like(stack)
-        self.reg_ref, self.batch, self.two_pass = reg_ref, batch, two_pass
+        self.reg_ref, self.batch, self.two_pass, self.tblock = reg_ref, batch, two_pass, tblock
         t, c, z, y, x = stack.shape
+        self.reg = torch.empty((tblock if tblock else t, c, z, y, x), dtype=torch.uint16, device=stack.device)
+        # the null threshold of SMO(shape, sigma, size) is a property of the plane shape, drawn once per FOV folder
+        # in the reference too (utility.py:252, outside its per-file loop): not part of the step
         self.thr = ops.smo_threshold((y, x), device=stack.device)
-        self.n_labels = ops.max_label(labels) + 1
 
     def step(self):
+        ops = self.ops
         if self.two_pass:
             if self.bg is None:
                 self.bg = torch.empty_like(self.raw)
-            ops.bg_smo(self.raw, self.thr, out=self.bg)
+            n_labels = ops.max_label(self.labels) + 1
+            _, self.levels, _ = ops.bg_smo(self.raw, self.thr, out=self.bg)
             _, self.shifts = ops.im_reg(self.bg, 0, self.reg_ref, upsample=True, batch=self.batch, out=self.reg)
+            self.tables = ops.measure_finalize(ops.measure_accumulate(self.reg, self.labels, n_labels))
         else:
-            levels, _ = ops.bg_smo_levels(self.raw, self.thr)
-            _, self.shifts = ops.im_reg(self.raw, 0, self.reg_ref, upsample=True, batch=self.batch, out=self.reg,
-                                        sub2=levels)
-        acc = ops.measure_accumulate(self.reg, self.labels, self.n_labels)
-        self.tables = ops.measure_finalize(acc)
+            self.tables, self.shifts, self.levels = ops.hot_path(self.raw, self.labels, self.thr, 0, self.reg_ref,
+                                                                 batch=self.batch, out=self.reg, tblock=self.tblock or None)
         return self.tables
-
-
-def pack_rows(tables, rank):
-    """per-cell rows {fov, frame, label, area, mean[C], cz, cy, cx} of the labels present, as one f64 matrix"""
-    area, mean, cen, _ = tables
-    t, L = area.shape
-    idx = torch.nonzero(area > 0)
-    f, l = idx[:, 0], idx[:, 1]
-    rows = torch.cat([torch.full((idx.shape[0], 1), float(rank), dtype=torch.float64, device=area.device),
-                      f[:, None].double(), l[:, None].double(), area[f, l][:, None].double(), mean[f, l], cen[f, l]], 1)
-    return rows
-
-
-def gather_rows(rows, world):
-    import torch.distributed as dist
-    n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n)
-    nmax = int(max(int(c.item()) for c in counts))
-    pad = torch.zeros((nmax, rows.shape[1]), dtype=rows.dtype, device=rows.device)
-    pad[: rows.shape[0]] = rows
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad)
-    return torch.cat([b[: int(c.item())] for b, c in zip(bufs, counts)], 0)
 
 
 def collect_kernel_times():
     import ctypes
+    from imageanalysis_pipeline_amd import _lib
     lib = _lib.load()
     out = {}
     for k in range(lib.iap_prof_kernel_count()):
@@ -171,10 +174,69 @@ def stream_copy_ceiling(dev, nbytes=1 << 30):
     return 2.0 * nbytes * 5 / (e0.elapsed_time(e1) / 1e3) / 1e9
 
 
+def verify(path, frames=(0, 1)):
+    """Ties the timed result to the oracle, stage by stage, on a few frames of the SAME device stack (the oracle
+    cannot run 500 frames): background levels exact; shift within 0.01 px of the oracle's estimate against the
+    same reference plane; warped pixels within 1 count of the oracle's warp at the same shift; tables bit-exact
+    against the oracle's measurement of the registered frame.  Raises AssertionError on a miss."""
+    from oracle import ref_path as O
+    ops = path.ops
+    raw, lab = path.raw, path.labels
+    t, c, z, y, x = raw.shape
+    frames = [f for f in frames if f < t]
+    levels = path.levels.view(t, c, z).cpu().numpy()
+    shifts = path.shifts.cpu().numpy()
+    area, mean, cen, cen_r = (a.cpu().numpy() for a in path.tables)
+    rep = {"frames": frames}
+    # reference plane of the registration channel: the lowered MIP planes summed by torch (checker only)
+    lv = ((path.levels.view(t, c, z)[:, 0] + 1) >> 1).clamp(0, 65535)
+    if path.reg_ref == "mean":
+        ref = torch.zeros((y, x), dtype=torch.float64, device=raw.device)
+        for f in range(t):
+            ref += (raw[f, 0].to(torch.int32) - lv[f].view(z, 1, 1)).clamp_(min=0).amax(dim=0).double()
+        ref = (ref / t).cpu().numpy()
+    elif path.reg_ref == "first":
+        ref = (raw[0, 0].to(torch.int32) - lv[0].view(z, 1, 1)).clamp_(min=0).amax(dim=0).double().cpu().numpy()
+    else:
+        ref = None
+    worst_shift, worst_px = 0.0, 0
+    for f in frames:
+        host = ops.to_numpy_u16(raw[f])                                # (C, Z, Y, X)
+        sub = np.empty_like(host)
+        for ch in range(c):
+            for k in range(z if z <= 2 else 1):                        # z-stacks: the first plane of each channel
+                out, med2, _, _ = O.bg_smo(host[ch, k], path.thr)
+                assert int(levels[f, ch, k]) == med2, f"background level of frame {f} channel {ch}: {levels[f, ch, k]} vs oracle {med2}"
+                sub[ch, k] = out
+        if ref is not None and z == 1 and not (path.reg_ref == "first" and f == 0):
+            dy, dx = O.phase_shift(ref, sub[0, 0].astype(np.float64))
+            worst_shift = max(worst_shift, abs(dy - shifts[f, 0]), abs(dx - shifts[f, 1]))
+        if path.tblock:
+            continue                                                    # the registered block buffer is reused
+        reg = ops.to_numpy_u16(path.reg[f])
+        for ch in sorted({0, c - 1}):
+            e = O.apply_shift(sub[ch, 0], shifts[f, 0], shifts[f, 1])
+            worst_px = max(worst_px, int(np.abs(e.astype(np.int64) - reg[ch, 0].astype(np.int64)).max()))
+        e = O.measure_labels(reg if z > 1 else reg[:, 0], ops.to_numpy_u16(lab[f]) if z > 1 else ops.to_numpy_u16(lab[f, 0]))
+        ids = e["ids"]
+        assert np.array_equal(np.nonzero(area[f])[0][1:], ids), f"label ids of frame {f}"
+        assert np.array_equal(area[f, ids], e["area"]), f"areas of frame {f}"
+        assert np.array_equal(mean[f, ids].view(np.uint64), e["mean"].view(np.uint64)), f"means of frame {f} are not bit-exact"
+        sl = slice(0, 3) if z > 1 else slice(1, 3)
+        assert np.array_equal(cen_r[f, ids][:, sl], e["centroid_rne"]), f"centroids of frame {f}"
+    assert worst_shift <= 0.01, f"shift differs from the oracle by {worst_shift} px"
+    assert worst_px <= 1, f"warped pixels differ from the oracle by {worst_px} counts"
+    rep.update({"background_levels": "exact", "max_shift_error_px": worst_shift, "max_warp_error_counts": worst_px,
+                "tables": "bit-exact (ids, areas, f64 means, rounded centroids)" if not path.tblock else "not checked (block buffer reused)",
+                "oracle": "oracle/ref_path.py on the frames listed, same device stack as the timed steps"})
+    return rep
+
+
 def cpu_baseline(y, x, c, n_cells, budget_frames=6, reg_ref="mean"):
     """The oracle (numpy restatement of the reference CPU path) on a bounded sample of the workload:
     `budget_frames` frames x C channels of the same plane size, same stages."""
     from oracle import ref_path as O
+    from imageanalysis_pipeline_amd import synth
     st, _ = synth.make_stack(budget_frames, c, 1, y, x, n_cells=n_cells, integer_drift=False)
     lab = synth.make_labels(y, x, n_cells)[None, None].repeat(budget_frames, 0) if n_cells else \
         synth.make_dense_labels(y, x)[None, None].repeat(budget_frames, 0)
@@ -198,6 +260,26 @@ def cpu_baseline(y, x, c, n_cells, budget_frames=6, reg_ref="mean"):
             "measure_s_per_frame": {"vectorised_bincount": t2 - t1, "reference_literal_loop": t3 - t2}}
 
 
+def live_traffic(dname, dstage, dims):
+    """HBM bytes per launch of the dominant kernel from rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: one run
+    each) over the library this process just timed, through its native harness.  (None, reason) when it cannot
+    run here (no rocprofv3, harness not built, already under a profiler)."""
+    if any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ):
+        return None, "running under a profiler: counter passes skipped"
+    if dstage not in HARNESS_OF_STAGE:
+        return None, f"no harness stage for {dstage}"
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import pmc_traffic
+        got = pmc_traffic.measure(HARNESS_OF_STAGE[dstage](*dims), timeout=150)
+        tr = got.get(dname)
+        if not tr:
+            return None, f"{dname} not among the profiled kernels {sorted(got)}"
+        return tr, None
+    except Exception as e:  # noqa: BLE001  (a bench line without traffic beats no line)
+        return None, f"{type(e).__name__}: {e}"[:300]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,24 +287,34 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=0, help="override T")
+    ap.add_argument("--tblock", type=int, default=-1, help="frames registered + measured at a time (0: whole stack)")
     ap.add_argument("--reg-ref", default="mean", choices=["first", "mean", "previous"],
                     help="reference frame of the registration; 'mean' is the reference's default (core.py:77) and what its notebook passes")
     ap.add_argument("--batch", type=int, default=64, help="frames per registration launch group")
     ap.add_argument("--two-pass", action="store_true", help="write the background-subtracted stack, then register it")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true")
     ap.add_argument("--stage-report", action="store_true", help="also print a per-kernel table to stderr")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))          # parent of the ranks: no GPU call has been made in this process
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP library is the only implementation)")
+    from imageanalysis_pipeline_amd import _lib, distributed
     # one rank per GPU.  IAP_BENCH_BACKEND=gloo is a rehearsal hook for boxes with fewer GPUs than
     # ranks (ranks then share devices and the table gather goes through host memory).
     backend = os.environ.get("IAP_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and local_rank >= ndev:
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({ndev} visible); one rank per GPU")
+    dev_index = local_rank if backend == "nccl" else local_rank % ndev
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
@@ -231,19 +323,27 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        world = dist.get_world_size()             # what the backend actually formed
+        if rank == 0 and world != args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but the launcher formed a world of {world}", file=sys.stderr)
 
-    t, c, z, y, x, n_cells = WORKLOADS[args.workload]
+    t, c, z, y, x, n_cells, tblock = WORKLOADS[args.workload]
     if args.frames:
         t = args.frames
+    if args.tblock >= 0:
+        tblock = args.tblock
+    if tblock >= t:
+        tblock = 0
+    if args.two_pass or args.reg_ref == "previous":
+        tblock = 0
     stack, labels, _ = make_device_stack(t, c, z, y, x, n_cells, dev, seed=rank)
-    path = Path(stack, labels, args.reg_ref, args.batch, args.two_pass)
+    path = Path(stack, labels, args.reg_ref, args.batch, args.two_pass, tblock)
     lib = _lib.load()
 
     def one_step():
         tables = path.step()
         if world > 1:
-            rows = pack_rows(tables, rank)
-            return gather_rows(rows if backend == "nccl" else rows.cpu(), world)
+            return distributed.gather_rows(distributed.pack_rows(tables, rank))
         return tables
 
     for _ in range(args.warmup):
@@ -313,19 +413,11 @@ def main():
                 "note": "achieved = stage algorithmic bytes (SURVEY 8d: %.3g B/px x stack px) / launches / mean launch "
                         "duration of the stage's dominant kernel (HIP events over the timed steps; the stage table "
                         "comes from one step profiled in full before them)" % bpp[dstage]}
-        prof = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(prof):
-            try:
-                tr = json.load(open(prof)).get(dname)
-                if tr:  # measured beforehand with rocprofv3 --pmc (separate passes), see profiles/
-                    roof["traffic"] = tr.get("hbm_bytes_per_launch")
-                    roof["traffic_detail"] = tr
-            except Exception:
-                pass
         if args.stage_report and rank == 0:
             for name, (ms, n) in sorted(ktimes_all.items(), key=lambda kv: -kv[1][0]):
                 print(f"  {name:28s} {ms:9.3f} ms/step  {n:6d} launches/step", file=sys.stderr)
 
+    out = None
     if rank == 0:
         out = {
             "metric": "Mpx/s through bg-sub+registration+mask measure",
@@ -333,8 +425,9 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u16", "data": "synthetic",
             "config": {"workload": f"{args.workload}: one FOV per GPU, T={t} C={c} Z={z} {y}x{x} uint16, sub-pixel drift, "
-                                   f"{n_cells or 5041} labels/frame, reg_ref={args.reg_ref}",
-                       "stages": "bg_smo + im_reg(estimate+apply) + measure_labels", "parallelism": f"fov-shard x{world}",
+                                   f"{n_cells or 5041} labels/frame, reg_ref={args.reg_ref}"
+                                   + (f", registered and measured {tblock} frames at a time" if tblock else ""),
+                       "stages": "max_label + bg_smo + im_reg(estimate+apply) + measure_labels", "parallelism": f"fov-shard x{world}",
                        "bg_subtraction": "written as a stack of its own, then registered" if args.two_pass else
                                          "applied on load by the registration kernels (same bits, no intermediate stack)"},
             "hbm_frac_end_to_end": value * 1e6 / world * total_bpp / HBM_PEAK,
@@ -345,7 +438,9 @@ def main():
             out["stage_hbm_frac"] = {k: bpp[k] * px_step / (v / 1e3) / HBM_PEAK for k, v in stages.items()}
         if roof:
             out["roofline"] = roof
-        if world == 1 and not args.two_pass:
+        if world == 1 and not args.no_verify:
+            out["verified"] = verify(path)            # raises (non-zero exit, no line) when the result is wrong
+        if world == 1 and not args.two_pass and not tblock:
             # the same path with the subtracted stack written out and read back: same outputs, one more pass
             path.two_pass = True
             path.step()
@@ -359,11 +454,22 @@ def main():
             path.bg = None
         if world == 1:
             out["stream_copy_ceiling_GBps"] = stream_copy_ceiling(dev)
+    if world > 1:
+        dist.destroy_process_group()
+    if rank == 0:
+        if world == 1 and roof and not args.no_traffic:
+            # free the stacks first: the harness allocates its own copy of the workload on the same GPU
+            del path, stack, labels
+            torch.cuda.empty_cache()
+            tr, why = live_traffic(roof["kernel"], roof["stage"], (t if not tblock else tblock, c, z, y, x))
+            if tr:
+                roof["traffic"] = tr["hbm_bytes_per_launch"]
+                roof["traffic_detail"] = tr
+            else:
+                roof["traffic_note"] = why
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(y, x, c, n_cells or 0, reg_ref=args.reg_ref)
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -44,7 +44,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Optional per-kernel timing with HIP events on the launch stream (iap_prof_* in iap.h).
 enum KernelId {
   K_SMO_MARCH = 0, K_SMO_GENERIC, K_MEDIAN, K_SUB, K_ROWS_R2C, K_COLS, K_ROWS_C2R, K_COARSE, K_UPSAMPLE,
-  K_UPFINISH, K_APPLY, K_MEASURE, K_MEASURE_FIN, K_MIP, K_ACCUM, K_GAUSS, K_ROI, K_OTHER, K_COUNT
+  K_UPFINISH, K_APPLY, K_MEASURE, K_MEASURE_FIN, K_MIP, K_ACCUM, K_GAUSS, K_ROI, K_MAXLABEL, K_OTHER, K_COUNT
 };
 extern bool g_prof_on;
 extern int g_prof_only;   // kernel id the recording is restricted to, -1: every kernel

@@ -40,7 +40,7 @@ const char* const k_names[K_COUNT] = {"smo_march_kernel", "smo_generic_kernel", 
                                       "rows_r2c_kernel", "cols_kernel", "rows_c2r_argmax_kernel",
                                       "coarse_finish_kernel", "upsample_partial_kernel", "upsample_finish_kernel",
                                       "apply_shift_kernel", "measure_kernel", "measure_finalize_kernel", "mip_kernel",
-                                      "accum_planes_kernel", "gauss_kernels", "roi_kernels", "other"};
+                                      "accum_planes_kernel", "gauss_kernels", "roi_kernels", "max_u16_kernel", "other"};
 }  // namespace
 
 void prof_mark(int kid, hipStream_t st, bool start) {

@@ -304,7 +304,7 @@ extern "C" int iap_max_u16(const uint16_t* labels, int64_t n, uint32_t* out, voi
   unsigned blocks = (unsigned)((nv + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   if (blocks == 0) blocks = 1;
-  { ProfScope ps_(K_OTHER, st); hipLaunchKernelGGL(max_u16_kernel, dim3(blocks), dim3(256), 0, st, labels, (long long)n, out); }
+  { ProfScope ps_(K_MAXLABEL, st); hipLaunchKernelGGL(max_u16_kernel, dim3(blocks), dim3(256), 0, st, labels, (long long)n, out); }
   IAP_LAUNCH_CHECK();
   return IAP_OK;
 }

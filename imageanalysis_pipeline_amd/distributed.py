@@ -68,10 +68,8 @@ def process_plate(load_fov, n_fov: int, threshold: float, reg_ref: str = "mean",
     parts = []
     for i in shard_fovs(n_fov, rank, world):
         stack, labels = load_fov(i)
-        levels, _ = ops.bg_smo_levels(stack, threshold)          # subtracted as im_reg reads the stack: the bits of
-        reg, _ = ops.im_reg(stack, reg_channel, reg_ref, sub2=levels)   # bg_smo followed by im_reg, one pass less
-        acc = ops.measure_accumulate(reg, labels)
-        parts.append(pack_rows(ops.measure_finalize(acc), i))
+        tables, _, _ = ops.hot_path(stack, labels, threshold, reg_channel, reg_ref)   # bg levels, im_reg, measure
+        parts.append(pack_rows(tables, i))
     if parts:
         rows = torch.cat(parts, 0)
     else:

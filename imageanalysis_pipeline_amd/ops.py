@@ -433,6 +433,49 @@ def im_reg(stack: torch.Tensor, reg_channel: int = 0, reg_ref: str = "mean", ups
     return out, shifts
 
 
+# ---------------------------------------------------------------- the whole path on one resident FOV
+def hot_path(stack: torch.Tensor, labels: torch.Tensor, threshold: float, reg_channel: int = 0, reg_ref: str = "mean",
+             upsample: bool = True, batch: int = DEFAULT_REG_BATCH, out: torch.Tensor | None = None,
+             tblock: int | None = None, n_labels: int | None = None, sigma: float = 0.0, size: int = 7):
+    """core.py:99-112 + 328-330 on a resident FOV: smo_bg_sub -> im_reg -> per-label tables.  ``stack`` u16
+    (T, C, Z, Y, X) raw, ``labels`` u16 (T, Z, Y, X).  Returns (tables, shifts, levels): tables as
+    ``measure_finalize``, shifts f64 (T, 2), levels int32 (T*C*Z,) = 2 x background of every plane.
+
+    The background levels are subtracted as the registration kernels read the raw stack (the bits of
+    ``bg_smo`` followed by ``im_reg``).  ``tblock``: the registered stack is produced and measured ``tblock`` frames
+    at a time into one reusable buffer (for stacks whose registered copy does not fit beside them, e.g. a
+    2048 x 2048 x 31 z x 2 ch x 200 frame stack); the estimate then runs on the z-MIPs of the lowered registration
+    channel, which are the planes ``im_reg`` estimates on, so shifts and tables equal the whole-stack call.
+    ``reg_ref='previous'`` needs the registered previous frame and is not offered block-wise."""
+    _need_cuda(stack, labels)
+    t, c, z, y, x = stack.shape
+    L = int(n_labels) if n_labels is not None else max_label(labels) + 1
+    levels, _ = bg_smo_levels(stack, threshold, sigma=sigma, size=size)
+    if not tblock or tblock >= t:
+        reg, shifts = im_reg(stack, reg_channel, reg_ref, upsample=upsample, batch=batch, out=out, sub2=levels)
+        return measure_finalize(measure_accumulate(reg, labels, L)), shifts, levels
+    if reg_ref == "previous":
+        raise ValueError("time blocks cannot run reg_ref='previous' (serial through the registered frames)")
+    planes = lowered_channel_mip(stack, reg_channel, levels)                       # (T, Y, X)
+    scratch = torch.empty_like(planes)
+    _, shifts = im_reg(planes.view(t, 1, 1, y, x), 0, reg_ref, upsample=upsample, batch=batch,
+                       out=scratch.view(t, 1, 1, y, x))
+    del scratch
+    lv = levels.view(t, c * z)
+    acc = torch.empty((t, L, 4 + c), dtype=torch.int64, device=stack.device)
+    buf = out if out is not None else torch.empty((tblock,) + tuple(stack.shape[1:]), dtype=torch.uint16, device=stack.device)
+    lib = _lib.load()
+    for t0 in range(0, t, tblock):
+        t1 = min(t, t0 + tblock)
+        nb = t1 - t0
+        _lib.check(lib.iap_apply_shift_sub_u16(stack[t0:t1].data_ptr(), buf.data_ptr(), nb, c * z, y, x,
+                                               shifts[t0:t1].data_ptr(), lv[t0:t1].data_ptr(), _stream()),
+                   "iap_apply_shift_sub_u16")
+        _lib.check(lib.iap_measure_labels_u16(buf.data_ptr(), labels[t0:t1].data_ptr(), nb, c, z, y, x, L,
+                                              acc[t0:t1].data_ptr(), _stream()), "iap_measure_labels_u16")
+    return measure_finalize(acc), shifts, levels
+
+
 # ---------------------------------------------------------------- distance map / pixel table (SURVEY 8f rank 2)
 def edt_sq(mask: torch.Tensor) -> torch.Tensor:
     """Squared Euclidean distance (int32, exact) of every pixel to the nearest non-zero pixel of ``mask``

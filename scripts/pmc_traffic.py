@@ -1,32 +1,112 @@
-"""Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter CSVs into profiles/traffic.json.
+"""HBM traffic per kernel launch from rocprofv3 counter passes over the in-tree libiap_hip.so.
 
-Usage: python scripts/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
-FETCH_SIZE / WRITE_SIZE are kilobytes at the L2's memory side; on gfx950 FETCH_SIZE tallies 128-byte
-requests at 64 bytes, so it is doubled (MI355X_MICROARCH.md, HBM section).  Values are per launch.
+`rocprofv3 --pmc` cannot profile python/torch on this image, so every pass runs scripts/pmc_harness (a native
+program that calls the library's C-ABI on the benchmark's shapes).  One run per counter: FETCH_SIZE and WRITE_SIZE
+do not fit one pass (MI355X_MICROARCH.md, rocprofv3 PMC slots).  Both are kilobytes at the L2's memory side; on
+gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, so it is doubled (same guide, HBM section).
+
+    python scripts/pmc_traffic.py apply 500 4                 # one stage, prints JSON
+    python scripts/pmc_traffic.py --all --out profiles/traffic.json
+
+bench.py imports `measure()` for the `roofline.traffic` field of its line.
 """
-import csv, json, re, sys, collections
+from __future__ import annotations
 
-def per_kernel(path, counter):
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HARNESS = os.path.join(ROOT, "scripts", "pmc_harness")
+
+
+def _per_kernel(path, counter):
     acc = collections.defaultdict(lambda: [0.0, 0])
-    for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] != counter or "iap::" not in r["Kernel_Name"]:
-            continue
-        m = re.search(r"iap::(\w+)", r["Kernel_Name"])
-        a = acc[m.group(1)]
-        a[0] += float(r["Counter_Value"]) * 1024.0
-        a[1] += 1
+    with open(path) as fh:
+        for r in csv.DictReader(fh):
+            if r["Counter_Name"] != counter or "iap::" not in r["Kernel_Name"]:
+                continue
+            a = acc[re.search(r"iap::(\w+)", r["Kernel_Name"]).group(1)]
+            a[0] += float(r["Counter_Value"]) * 1024.0
+            a[1] += 1
     return acc
 
-fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
-write = per_kernel(sys.argv[2], "WRITE_SIZE")
-out = {}
-for k in sorted(set(fetch) | set(write)):
-    f, nf = fetch.get(k, [0.0, 0]); w, nw = write.get(k, [0.0, 0])
-    fb = 2.0 * f / nf if nf else None
-    wb = w / nw if nw else None
-    out[k] = {"hbm_bytes_per_launch": (fb or 0.0) + (wb or 0.0), "fetch_bytes_per_launch": fb,
-              "write_bytes_per_launch": wb, "launches_sampled": max(nf, nw),
-              "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, rocprofv3 --pmc, separate passes"}
-json.dump(out, open(sys.argv[3], "w"), indent=1)
-for k, v in out.items():
-    print(f"{k:28s} fetch {v['fetch_bytes_per_launch'] or 0:14.0f}  write {v['write_bytes_per_launch'] or 0:14.0f}  launches {v['launches_sampled']}")
+
+def _pass(counter, harness_args, workdir, timeout):
+    out = os.path.join(workdir, counter)
+    cmd = ["rocprofv3", "--pmc", counter, "-d", out, "-o", "p", "--output-format", "csv", "--", HARNESS] + [str(a) for a in harness_args]
+    env = dict(os.environ, IAP_HARNESS_REPS="2")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, env=env, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"{' '.join(cmd)} -> {r.returncode}: {r.stderr[-400:]}")
+    files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        raise RuntimeError(f"no counter_collection.csv under {out}")
+    timing = None
+    for line in r.stdout.splitlines():
+        if line.startswith("{"):
+            timing = json.loads(line)
+    return _per_kernel(files[0], counter), timing
+
+
+def measure(harness_args, timeout=120, keep=None):
+    """{kernel: {hbm_bytes_per_launch, fetch_bytes_per_launch, write_bytes_per_launch, launches_sampled}} for one
+    harness invocation, e.g. measure(["apply", 500, 4]).  Raises when rocprofv3 or the harness is unavailable."""
+    if not os.access(HARNESS, os.X_OK):
+        raise RuntimeError(f"{HARNESS} is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    if shutil.which("rocprofv3") is None:
+        raise RuntimeError("rocprofv3 not on PATH")
+    work = keep or tempfile.mkdtemp(prefix="iap_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    os.makedirs(work, exist_ok=True)
+    try:
+        fetch, timing = _pass("FETCH_SIZE", harness_args, work, timeout)
+        write, _ = _pass("WRITE_SIZE", harness_args, work, timeout)
+    finally:
+        if keep is None:
+            shutil.rmtree(work, ignore_errors=True)
+    out = {}
+    for k in sorted(set(fetch) | set(write)):
+        f, nf = fetch.get(k, [0.0, 0])
+        w, nw = write.get(k, [0.0, 0])
+        fb = 2.0 * f / nf if nf else None
+        wb = w / nw if nw else None
+        out[k] = {"hbm_bytes_per_launch": (fb or 0.0) + (wb or 0.0), "fetch_bytes_per_launch": fb,
+                  "write_bytes_per_launch": wb, "launches_sampled": max(nf, nw),
+                  "config": "scripts/pmc_harness " + " ".join(str(a) for a in harness_args) + " (C-ABI of libiap_hip.so)",
+                  "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, rocprofv3 --pmc, one pass per counter"}
+        if timing:
+            out[k]["harness_ms_per_call_under_profiler"] = timing.get("ms_per_call")
+    return out
+
+
+ALL = (["apply", 500, 4], ["bg", 2000], ["estimate", 128], ["measure", 500, 4], ["measure", 16, 1, 2048, 2048, "dense"])
+
+
+if __name__ == "__main__":
+    args = sys.argv[1:]
+    outp = None
+    if "--out" in args:
+        i = args.index("--out")
+        outp = args[i + 1]
+        del args[i:i + 2]
+    runs = ALL if "--all" in args else [args]
+    res = {}
+    for ha in runs:
+        got = measure(ha)
+        for k, v in got.items():
+            key = k if k not in res else f"{k} ({' '.join(str(a) for a in ha)})"
+            res[key] = v
+            print(f"{key:44s} fetch {v['fetch_bytes_per_launch'] or 0:16.0f}  write {v['write_bytes_per_launch'] or 0:16.0f}  "
+                  f"launches {v['launches_sampled']}", flush=True)
+    if outp:
+        with open(outp, "w") as fh:
+            json.dump(res, fh, indent=1)
+    else:
+        print(json.dumps(res))
