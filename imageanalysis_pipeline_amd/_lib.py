@@ -22,6 +22,7 @@ SIGNATURES = {
     "iap_bg_smo_ws_bytes": (_sz, [_i64, _i32, _i32, _f32]),
     "iap_bg_smo_u16": (_i32, [_vp, _vp, _i64, _i32, _i32, _f32, _i32, _f32, _vp, _vp, _vp, _sz, _vp]),
     "iap_bg_const_u16": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "iap_bg_const_static_u16": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "iap_gauss_blur_u16": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp]),
     "iap_mip_u16": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp]),
     "iap_mip_sub_u16": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),

@@ -18,6 +18,7 @@
 // 1024-value window around the strip's first pixels (background is narrow); anything outside
 // goes straight to HBM atomics.
 #include <stdlib.h>
+#include <mutex>
 #include "common.h"
 
 namespace iap {
@@ -722,6 +723,12 @@ static int launch_gauss_reflect(const T* in, float* tmp, float* out, int64_t n, 
   return IAP_OK;
 }
 
+// Scratch of iap_bg_const_static_u16 (the entry point that allocates nothing): the ROI sums (u64) and doubled
+// levels (int) of up to IAP_BG_CONST_STATIC_MAX_PLANES planes, 16 bytes a plane.  Every GPU the library runs on
+// holds its own copy until the process ends.  Host code never passes the array's name to a kernel or a memset: it
+// is a host-side stand-in there; the device address comes from hipGetSymbolAddress, once per device.
+static __device__ __align__(256) unsigned char scratch[IAP_BG_CONST_STATIC_MAX_PLANES * 16];
+
 constexpr int64_t BG_BATCH_BYTES = 2048ll << 20;  // planes per batch: long launches hide the march tail (C2 bg stage, levels only: 128 MB 18.2, 1 GB 8.95, 2 GB 8.5 ms)
 
 }  // namespace iap
@@ -846,18 +853,9 @@ extern "C" int iap_bg_smo_u16(const uint16_t* in, uint16_t* out, int64_t n, int 
   return IAP_OK;
 }
 
-extern "C" int iap_bg_const_u16(const uint16_t* in, uint16_t* out, int64_t n, int Y, int X, int r0, int c0,
-                                int r1, int c1, int32_t* bg_out, void* ws, size_t ws_bytes, void* stream) {
-  int rc = check_plane_args("iap_bg_const_u16", in, out, n, Y, X);
-  if (rc) return rc;
-  IAP_REQUIRE(0 <= r0 && r0 <= r1 && r1 < Y && 0 <= c0 && c0 <= c1 && c1 < X, IAP_E_ARG,
-              "iap_bg_const_u16: ROI (%d,%d)-(%d,%d) outside the %dx%d plane", r0, c0, r1, c1, Y, X);
-  IAP_REQUIRE(ws && aligned16(ws) && ws_bytes >= (size_t)n * 16, IAP_E_WS,
-              "iap_bg_const_u16: workspace must hold n*16 bytes");
-  IAP_REQUIRE(n <= 65535, IAP_E_UNSUPPORTED, "iap_bg_const_u16: n must be <= 65535 per call");
-  hipStream_t st = as_stream(stream);
-  unsigned long long* sums = (unsigned long long*)ws;
-  int* bg2 = (int*)(sums + n);
+// ROI sums -> level per plane -> subtraction; `sums` (u64[n]) and `bg2` (int[n]) are device scratch
+static int bg_const_run(const uint16_t* in, uint16_t* out, int64_t n, int Y, int X, int r0, int c0, int r1, int c1,
+                        int32_t* bg_out, unsigned long long* sums, int* bg2, hipStream_t st) {
   IAP_HIP(hipMemsetAsync(sums, 0, (size_t)n * 8, st));
   long long n_roi = (long long)(r1 - r0 + 1) * (c1 - c0 + 1);
   unsigned gx = (unsigned)((n_roi + 255) / 256);
@@ -873,6 +871,59 @@ extern "C" int iap_bg_const_u16(const uint16_t* in, uint16_t* out, int64_t n, in
   { ProfScope ps_(K_SUB, st); hipLaunchKernelGGL(sub_half_kernel, dim3(sx, (unsigned)n), dim3(256), 0, st, in, out, px, (const int*)bg2); }
   IAP_LAUNCH_CHECK();
   return IAP_OK;
+}
+
+static int bg_const_check(const char* fn, const uint16_t* in, uint16_t* out, int64_t n, int Y, int X, int r0, int c0,
+                          int r1, int c1) {
+  int rc = check_plane_args(fn, in, out, n, Y, X);
+  if (rc) return rc;
+  IAP_REQUIRE(0 <= r0 && r0 <= r1 && r1 < Y && 0 <= c0 && c0 <= c1 && c1 < X, IAP_E_ARG,
+              "%s: ROI (%d,%d)-(%d,%d) outside the %dx%d plane", fn, r0, c0, r1, c1, Y, X);
+  return IAP_OK;
+}
+
+extern "C" int iap_bg_const_u16(const uint16_t* in, uint16_t* out, int64_t n, int Y, int X, int r0, int c0,
+                                int r1, int c1, int32_t* bg_out, void* ws, size_t ws_bytes, void* stream) {
+  int rc = bg_const_check("iap_bg_const_u16", in, out, n, Y, X, r0, c0, r1, c1);
+  if (rc) return rc;
+  IAP_REQUIRE(ws && aligned16(ws) && ws_bytes >= (size_t)n * 16, IAP_E_WS,
+              "iap_bg_const_u16: workspace must hold n*16 bytes");
+  IAP_REQUIRE(n <= 65535, IAP_E_UNSUPPORTED, "iap_bg_const_u16: n must be <= 65535 per call");
+  unsigned long long* sums = (unsigned long long*)ws;
+  return bg_const_run(in, out, n, Y, X, r0, c0, r1, c1, bg_out, sums, (int*)(sums + n), as_stream(stream));
+}
+
+// Device address of `scratch` on the current device, resolved once per device (with that device current) and kept.
+static int static_scratch(unsigned char** ptr) {
+  static std::mutex mu;
+  static unsigned char* per_device[64] = {nullptr};
+  int dev = -1;
+  IAP_HIP(hipGetDevice(&dev));
+  IAP_REQUIRE(dev >= 0 && dev < 64, IAP_E_UNSUPPORTED, "iap_bg_const_static_u16: device index %d out of range", dev);
+  std::lock_guard<std::mutex> lk(mu);
+  if (!per_device[dev]) {
+    void* p = nullptr;
+    IAP_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    IAP_REQUIRE(p != nullptr, IAP_E_UNSUPPORTED, "iap_bg_const_static_u16: hipGetSymbolAddress returned a null address");
+    per_device[dev] = (unsigned char*)p;
+  }
+  *ptr = per_device[dev];
+  return IAP_OK;
+}
+
+extern "C" int iap_bg_const_static_u16(const uint16_t* in, uint16_t* out, int64_t n, int Y, int X, int r0, int c0,
+                                       int r1, int c1, int32_t* bg_out, void* stream) {
+  int rc = bg_const_check("iap_bg_const_static_u16", in, out, n, Y, X, r0, c0, r1, c1);
+  if (rc) return rc;
+  IAP_REQUIRE(n <= IAP_BG_CONST_STATIC_MAX_PLANES, IAP_E_UNSUPPORTED,
+              "iap_bg_const_static_u16: %lld planes exceed the static scratch (at most %d per call; use "
+              "iap_bg_const_u16 with a workspace, or split the call)", (long long)n, IAP_BG_CONST_STATIC_MAX_PLANES);
+  unsigned char* ptr = nullptr;
+  rc = static_scratch(&ptr);
+  if (rc) return rc;
+  // the array keeps the last call's contents: bg_const_run zeroes the sums it adds into; the levels are overwritten
+  unsigned long long* sums = (unsigned long long*)ptr;
+  return bg_const_run(in, out, n, Y, X, r0, c0, r1, c1, bg_out, sums, (int*)(sums + n), as_stream(stream));
 }
 
 extern "C" int iap_gauss_blur_u16(const uint16_t* in, uint16_t* out, int64_t n, int Y, int X, int kx, int ky,

@@ -69,6 +69,17 @@ int iap_bg_const_u16(const uint16_t* in, uint16_t* out, int64_t n, int Y, int X,
                      int r0, int c0, int r1, int c1, int32_t* bg_out,
                      void* ws, size_t ws_bytes, void* stream);
 
+/* The same computation as iap_bg_const_u16 for callers that cannot allocate or carry a workspace (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.
+ * The ROI sums and levels live in a file-scope device array of the library (IAP_BG_CONST_STATIC_MAX_PLANES * 16
+ * bytes = 64 KiB on every GPU the library runs on, held until the process ends); the call makes no hipMalloc /
+ * hipFree and takes no workspace.  n above IAP_BG_CONST_STATIC_MAX_PLANES is refused with IAP_E_UNSUPPORTED.  Call
+ * it with the stream's device current.  All calls on one GPU share that array: calls that overlap in time on one
+ * GPU (different streams or threads) race; calls in stream order are safe. */
+#define IAP_BG_CONST_STATIC_MAX_PLANES 4096
+int iap_bg_const_static_u16(const uint16_t* in, uint16_t* out, int64_t n, int Y, int X,
+                            int r0, int c0, int r1, int c1, int32_t* bg_out, void* stream);
+
 /* utility.py:462 blur_img: cv2.GaussianBlur(im,(kx,ky),sigma).astype(uint16) semantics,
  * reflect-101 border, fp32 taps, round-half-even + saturate.  kx, ky odd, <= 63. */
 int iap_gauss_blur_u16(const uint16_t* in, uint16_t* out, int64_t n, int Y, int X,
