@@ -3,10 +3,12 @@
 // estimator here is the FFT cross-power scheme north_star asks for).
 //
 // Estimate, per moving plane (all on device, no host round trip):
-//   K1 rows_r2c      u16 rows -> half spectrum, two real rows per complex FFT (LDS Stockham)
+//   K1 rows_r2c      u16 rows -> half spectrum, two real rows per complex FFT (LDS Stockham); stored as
+//                    packed half pairs (the reference plane's: float)
 //   K2 cols_xpower   column FFT, * conj-multiply with the reference spectrum (DC zeroed,
 //                    optional phase normalisation), inverse column FFT in the same LDS tile,
-//                    write back in place: Q[y][v], spatial along y, spectral along x
+//                    written as float Q[y][v], spatial along y, spectral along x; the reference's tile stays
+//                    in registers while a workgroup walks its frames, the next frame's tile is in flight
 //   K3 rows_c2r_argmax  inverse row FFT + wave-shuffle / LDS arg-max (correlation surface is
 //                    never written to HBM)
 //   K4 coarse peak      arg-max over the per-workgroup partials -> signed integer shift: done by K5's table
@@ -237,10 +239,24 @@ __device__ __forceinline__ float load_src(const void* __restrict__ p, int kind, 
 }
 
 // K1 ---------------------------------------------------------------------------------------
-template <int N>
+// Row spectra are stored in one of two forms.  The moving planes' (always u16 data, so |F| <= Px * 65535) go
+// to HBM as packed half pairs, scaled by FS16<N> = 0.5 / Px: half the bytes of the path's largest scratch
+// stream, and small enough for the column kernel to keep the next frame's tile in flight in registers.  The
+// rounding is harmless here (relative 2^-12 on coefficients that carry 1e-2 .. 1 of photon noise each;
+// measured on the synthetic stacks: 3e-5 px, scripts/f16_spectra_sim.py); the same rounding on Q is not
+// (1e-2 px: the refinement differences neighbouring values of a broad peak), so Q stays float.  The reference
+// plane's row spectrum (any of the three source kinds, unbounded for float) stays float on its way to mode 0.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ h2 to_h2(cf v) { return __builtin_convertvector(v, h2); }
+__device__ __forceinline__ cf from_h2(h2 v) { return __builtin_convertvector(v, cf); }
+template <int N> constexpr float fs16() { return 0.5f / (float)N; }
+
+template <int N, bool OUT16>
 __global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_r2c_kernel(
     const void* __restrict__ src, int kind, long long plane_stride, int srcX, int oy, int ox, float in_scale,
-    cf* __restrict__ F, long long F_stride, int Wp, const cf* __restrict__ tw, int vec,
+    void* __restrict__ Fv, long long F_stride, int Wp, const cf* __restrict__ tw, int vec,
     const int* __restrict__ sub2, long long sub_stride) {
   using Gm = FftGeom<N>;
   extern __shared__ cf lds_c[];
@@ -252,6 +268,7 @@ __global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_r2c_kernel
   const size_t base = (size_t)blockIdx.y * plane_stride;
   const size_t offa = base + (size_t)(oy + ra) * srcX + ox;
   const size_t offb = offa + srcX;
+  if (OUT16) in_scale *= fs16<N>();
   if (vec) {  // u16 source, 16-byte aligned rows: one 8-pixel vector per row and thread
     const uint16_t* p16 = reinterpret_cast<const uint16_t*>(src);
     u16x8 qa = load8(p16 + offa + 8 * j), qb = load8(p16 + offb + 8 * j);
@@ -273,149 +290,269 @@ __global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_r2c_kernel
   }
   __syncthreads();
   fft_lds<N, -1>(s, j, tw);
-  cf* Fa = F + (size_t)blockIdx.y * F_stride + (size_t)ra * Wp;
-  cf* Fb = Fa + Wp;
-  for (int k = j; k <= N / 2; k += Gm::NT) {
-    cf zk = s[padi<8>(k)];
-    cf zn = s[padi<8>((N - k) & (N - 1))];
-    Fa[k] = mkc(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-    Fb[k] = mkc(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+  if (OUT16) {
+    h2* Fa = reinterpret_cast<h2*>(Fv) + (size_t)blockIdx.y * F_stride + (size_t)ra * Wp;
+    h2* Fb = Fa + Wp;
+    for (int k = j; k <= N / 2; k += Gm::NT) {
+      cf zk = s[padi<8>(k)];
+      cf zn = s[padi<8>((N - k) & (N - 1))];
+      Fa[k] = to_h2(mkc(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y)));
+      Fb[k] = to_h2(mkc(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x)));
+    }
+  } else {
+    cf* Fa = reinterpret_cast<cf*>(Fv) + (size_t)blockIdx.y * F_stride + (size_t)ra * Wp;
+    cf* Fb = Fa + Wp;
+    for (int k = j; k <= N / 2; k += Gm::NT) {
+      cf zk = s[padi<8>(k)];
+      cf zn = s[padi<8>((N - k) & (N - 1))];
+      Fa[k] = mkc(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+      Fb[k] = mkc(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+    }
   }
 }
 
 // K2 ---------------------------------------------------------------------------------------
-// mode 0: forward column FFT of the reference; the spectrum is written to R in TILE-MAJOR order
-//         (the TC columns x N rows of a workgroup form one contiguous block), because every
-//         moving frame re-reads it tile by tile: contiguous 16-byte-per-lane reads instead of
-//         32-byte row pieces.
-// mode 1: forward FFT, P = G * conj(F) * scale (DC = 0, optional /|P|) with G = Gref (tile-major; one for
-//         all frames, G_stride = 0, or one per frame), inverse FFT, store back to F in place (R unused).
-// mode 2: as mode 1, but Gref is the reference's ROW-pass spectrum in F's own layout: its column FFT runs
-//         in a second LDS tile of the same workgroup (the serial 'previous' chain: one launch fewer per
-//         frame; the launch passes twice the LDS).  An instantiation of its own (FUSED), so that the
-//         batch modes keep their register budget.
-template <int N, bool FUSED>
-__global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, FUSED ? 2 : 4) void cols_kernel(
-    cf* __restrict__ F, long long F_stride, const cf* __restrict__ Gref, long long G_stride, cf* __restrict__ R,
-    long long R_stride, int Wp, const cf* __restrict__ tw, int mode, int normalize, float scale) {
+// Column pass on tiles of TC columns (XCD-remapped so that neighbouring tiles, which share cache lines of the
+// row-major spectra, run on one L2).  Half-precision tiles move in chunks of VW = min(TC, 4) complex values
+// (16 bytes for TC >= 4): a thread owns the chunks idx = tid + m * NTH, m < NL; chunk idx covers row
+// u = idx / CPR, columns (idx % CPR) * VW .. + VW - 1 of the tile (CPR = TC / VW chunks per row).
+//   cols_ref_kernel     the reference: float row spectrum -> column FFT -> G as half pairs in TILE-MAJOR chunk
+//                       order (what the threads of the cross-power kernel read: contiguous 16 bytes per lane),
+//                       scaled per tile by a power of two so that any float reference fits (gscale[tile] = the
+//                       factor that undoes it).
+//   cols_xpower_kernel  the moving frames, one (tile, frame) per workgroup: half tile -> LDS, column FFT,
+//                       P = G conj(F) (DC zeroed, optional / |P|; G one for all frames or one per frame: channel
+//                       shift pairs), inverse FFT, Q[y][v] stored as float (spatial along y, spectral along x).
+//                       (Measured and dropped: a workgroup walking several frames with the next tile's 16
+//                       registers in flight under the FFTs -- the 16-point passes already fill the 128 registers
+//                       of 4 waves/SIMD, 19 spill: 15.1 instead of 13.1 us/frame; the kernel is bound by LDS and
+//                       barrier latency at 4 waves per SIMD, not by its streams: halving them changed nothing.)
+//   cols_fused_kernel   the serial 'previous' chain: the reference arrives as its ROW spectrum (half pairs, F's
+//                       layout) and gets its column FFT in a second LDS tile of the same workgroup.
+template <int N>
+struct ColGeom {
   using Gm = FftGeom<N>;
-  constexpr int NTH = Gm::TC * Gm::CNT;
-  extern __shared__ cf lds_c[];
-  const int tid = threadIdx.x;
-  const int c = tid / Gm::CNT, j = tid % Gm::CNT;
-  cf* s = lds_c + c * Gm::CS;
-  const unsigned frame = blockIdx.y;
-  const int v0 = xcd_remap(blockIdx.x, gridDim.x) * Gm::TC;
-  cf* Ff = F + (size_t)frame * F_stride;
-  // Tile rows are TC complex values (32 bytes for N = 2048): every lane moves TWO neighbouring columns of
-  // one row as one 16-byte access (half the memory instructions of an 8-byte-per-lane mapping).
-  static_assert(Gm::TC % 2 == 0 && Gm::CE % 2 == 0, "column pairs");
-  constexpr int HP = Gm::TC / 2;                 // column pairs per row
-  {
-    float4 w[Gm::CE / 2];                        // all of the thread's loads in flight together
+  static constexpr int TC = Gm::TC, CE = Gm::CE, CNT = Gm::CNT, CS = Gm::CS;
+  static constexpr int NTH = TC * CNT;
+  static constexpr int VW = TC < 4 ? TC : 4;     // complex values per half-precision chunk
+  static constexpr int CPR = TC / VW;            // chunks per tile row
+  static constexpr int NL = CE / VW;             // chunks per thread
+  static_assert(TC % VW == 0 && CE % VW == 0 && (TC * N) % (NTH * VW) == 0, "whole chunks per thread");
+  static_assert(TC % 2 == 0 && CE % 2 == 0, "column pairs for the float stores");
+};
+template <int VW> struct HChunk;
+template <> struct HChunk<4> { typedef h8 T; };
+template <> struct HChunk<2> { typedef h4 T; };
+
+// half tile (row-major spectrum F, Wp values per row) -> registers; columns past `nvalid` read as zero
+template <int N>
+__device__ __forceinline__ void load_half_tile(const h2* __restrict__ Ff, int Wp, int v0, int tid,
+                                               typename HChunk<ColGeom<N>::VW>::T (&w)[ColGeom<N>::NL]) {
+  using Cg = ColGeom<N>;
+  typedef typename HChunk<Cg::VW>::T HC;
 #pragma unroll
-    for (int m = 0; m < Gm::CE / 2; ++m) {
-      const int idx = tid + m * NTH;             // pair index: (row u, pair pc)
+  for (int m = 0; m < Cg::NL; ++m) {
+    const int idx = tid + m * Cg::NTH;
+    w[m] = *reinterpret_cast<const HC*>(Ff + (size_t)(idx / Cg::CPR) * Wp + v0 + (idx % Cg::CPR) * Cg::VW);
+  }
+}
+template <int N>
+__device__ __forceinline__ void stage_half_tile(cf* lds, int v0, int nvalid, int tid,
+                                                const typename HChunk<ColGeom<N>::VW>::T (&w)[ColGeom<N>::NL]) {
+  using Cg = ColGeom<N>;
+#pragma unroll
+  for (int m = 0; m < Cg::NL; ++m) {
+    const int idx = tid + m * Cg::NTH;
+    const int u = idx / Cg::CPR, c0 = (idx % Cg::CPR) * Cg::VW;
+#pragma unroll
+    for (int h = 0; h < Cg::VW; ++h) {
+      cf v = from_h2((h2){w[m][2 * h], w[m][2 * h + 1]});
+      if (v0 + c0 + h >= nvalid) v = mkc(0.f, 0.f);   // padding columns hold whatever the workspace held
+      lds[(c0 + h) * Cg::CS + padi<Cg::CE>(u)] = v;
+    }
+  }
+}
+// Q tile (LDS) -> float row-major spectrum, two neighbouring columns per 16-byte store
+template <int N>
+__device__ __forceinline__ void store_float_tile(const cf* lds, cf* __restrict__ Qf, int Wp, int v0, int tid) {
+  using Cg = ColGeom<N>;
+  constexpr int HP = Cg::TC / 2;
+#pragma unroll 4
+  for (int m = 0; m < Cg::CE / 2; ++m) {
+    const int idx = tid + m * Cg::NTH;
+    const int pc = idx % HP, u = idx / HP;
+    const cf a = lds[(2 * pc) * Cg::CS + padi<Cg::CE>(u)], b2 = lds[(2 * pc + 1) * Cg::CS + padi<Cg::CE>(u)];
+    *reinterpret_cast<float4*>(Qf + (size_t)u * Wp + v0 + 2 * pc) = make_float4(a.x, a.y, b2.x, b2.y);
+  }
+}
+__device__ __forceinline__ cf xpower(cf g, cf f, float scale, int normalize) {
+  cf p = mkc((f.x * g.x + f.y * g.y) * scale, (f.y * g.x - f.x * g.y) * scale);   // f conj(g): g = the moving frame's value, f = the reference's
+  if (normalize) {
+    float m2 = p.x * p.x + p.y * p.y;
+    float inv = m2 > 0.f ? rsqrtf(m2) : 0.f;
+    p.x *= inv;
+    p.y *= inv;
+  }
+  return p;
+}
+
+template <int N>
+__global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_ref_kernel(
+    const cf* __restrict__ F, long long F_stride, h2* __restrict__ G, long long G_stride, float* __restrict__ gscale,
+    int gs_stride, int Wp, int nvalid, const cf* __restrict__ tw) {
+  using Cg = ColGeom<N>;
+  typedef typename HChunk<Cg::VW>::T HC;
+  extern __shared__ cf lds_c[];
+  __shared__ float wmax[16];
+  const int tid = threadIdx.x;
+  const int c = tid / Cg::CNT, j = tid % Cg::CNT;
+  const unsigned frame = blockIdx.y;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x), v0 = tile * Cg::TC;
+  const cf* Ff = F + (size_t)frame * F_stride;
+  constexpr int HP = Cg::TC / 2;
+  {
+    float4 w[Cg::CE / 2];
+#pragma unroll
+    for (int m = 0; m < Cg::CE / 2; ++m) {
+      const int idx = tid + m * Cg::NTH;
       w[m] = *reinterpret_cast<const float4*>(Ff + (size_t)(idx / HP) * Wp + v0 + 2 * (idx % HP));
     }
 #pragma unroll
-    for (int m = 0; m < Gm::CE / 2; ++m) {
-      const int idx = tid + m * NTH;
+    for (int m = 0; m < Cg::CE / 2; ++m) {
+      const int idx = tid + m * Cg::NTH;
       const int pc = idx % HP, u = idx / HP;
-      lds_c[(2 * pc) * Gm::CS + padi<Gm::CE>(u)] = mkc(w[m].x, w[m].y);
-      lds_c[(2 * pc + 1) * Gm::CS + padi<Gm::CE>(u)] = mkc(w[m].z, w[m].w);
-    }
-  }
-  cf* const lds_g = lds_c + Gm::TC * Gm::CS;     // mode 2: the reference's tile
-  if (FUSED) {
-    const cf* Gf = Gref + (size_t)frame * G_stride;
-    float4 w[Gm::CE / 2];
-#pragma unroll
-    for (int m = 0; m < Gm::CE / 2; ++m) {
-      const int idx = tid + m * NTH;
-      w[m] = *reinterpret_cast<const float4*>(Gf + (size_t)(idx / HP) * Wp + v0 + 2 * (idx % HP));
-    }
-#pragma unroll
-    for (int m = 0; m < Gm::CE / 2; ++m) {
-      const int idx = tid + m * NTH;
-      const int pc = idx % HP, u = idx / HP;
-      lds_g[(2 * pc) * Gm::CS + padi<Gm::CE>(u)] = mkc(w[m].x, w[m].y);
-      lds_g[(2 * pc + 1) * Gm::CS + padi<Gm::CE>(u)] = mkc(w[m].z, w[m].w);
+      const bool oka = v0 + 2 * pc < nvalid, okb = v0 + 2 * pc + 1 < nvalid;
+      lds_c[(2 * pc) * Cg::CS + padi<Cg::CE>(u)] = oka ? mkc(w[m].x, w[m].y) : mkc(0.f, 0.f);
+      lds_c[(2 * pc + 1) * Cg::CS + padi<Cg::CE>(u)] = okb ? mkc(w[m].z, w[m].w) : mkc(0.f, 0.f);
     }
   }
   __syncthreads();
-  fft_lds<N, -1, Gm::CE>(s, j, tw);
-  if (FUSED) {
-    fft_lds<N, -1, Gm::CE>(lds_g + c * Gm::CS, j, tw);
+  fft_lds<N, -1, Cg::CE>(lds_c + c * Cg::CS, j, tw);
+  // largest component of the tile -> power-of-two scale that brings it into [16384, 32768)
+  cf v[Cg::NL][Cg::VW];
+  float mx = 0.f;
 #pragma unroll
-    for (int m = 0; m < Gm::CE / 2; ++m) {
-      const int idx = tid + m * NTH;
-      const int pc = idx % HP, u = idx / HP;
+  for (int m = 0; m < Cg::NL; ++m) {
+    const int idx = tid + m * Cg::NTH;
+    const int u = idx / Cg::CPR, c0 = (idx % Cg::CPR) * Cg::VW;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int at = (2 * pc + h) * Gm::CS + padi<Gm::CE>(u);
-        const cf g = lds_c[at], f = lds_g[at];
-        cf p = mkc((f.x * g.x + f.y * g.y) * scale, (f.y * g.x - f.x * g.y) * scale);
-        if (normalize) {
-          float m2 = p.x * p.x + p.y * p.y;
-          float inv = m2 > 0.f ? rsqrtf(m2) : 0.f;
-          p.x *= inv;
-          p.y *= inv;
-        }
-        if (u == 0 && v0 + 2 * pc + h == 0) p = mkc(0.f, 0.f);
+    for (int h = 0; h < Cg::VW; ++h) {
+      v[m][h] = lds_c[(c0 + h) * Cg::CS + padi<Cg::CE>(u)];
+      mx = fmaxf(mx, fmaxf(fabsf(v[m][h].x), fabsf(v[m][h].y)));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((tid & 63) == 0) wmax[tid >> 6] = mx;
+  __syncthreads();
+  mx = 0.f;
+  for (int k = 0; k < Cg::NTH / 64; ++k) mx = fmaxf(mx, wmax[k]);
+  int ex = 0;
+  float sc = 1.f;
+  if (mx > 0.f && mx < INFINITY) {
+    (void)frexpf(mx, &ex);          // mx = m 2^ex, m in [0.5, 1)
+    sc = ldexpf(1.f, 15 - ex);
+  }
+  if (tid == 0) gscale[(size_t)frame * gs_stride + tile] = 1.0f / sc;
+  h2* Gt = G + (size_t)frame * G_stride + (size_t)v0 * N;
+#pragma unroll
+  for (int m = 0; m < Cg::NL; ++m) {
+    const int idx = tid + m * Cg::NTH;
+    HC o;
+#pragma unroll
+    for (int h = 0; h < Cg::VW; ++h) {
+      const h2 q = to_h2(v[m][h] * (cf){sc, sc});
+      o[2 * h] = q.x;
+      o[2 * h + 1] = q.y;
+    }
+    *reinterpret_cast<HC*>(Gt + (size_t)idx * Cg::VW) = o;
+  }
+}
+
+template <int N>
+__global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_xpower_kernel(
+    const h2* __restrict__ F, long long F_stride, const h2* __restrict__ G, long long G_stride,
+    const float* __restrict__ gscale, int gs_stride, cf* __restrict__ Q, long long Q_stride, int Wp, int nvalid,
+    const cf* __restrict__ tw, int normalize, float scale) {
+  using Cg = ColGeom<N>;
+  typedef typename HChunk<Cg::VW>::T HC;
+  extern __shared__ cf lds_c[];
+  const int tid = threadIdx.x;
+  const int c = tid / Cg::CNT, j = tid % Cg::CNT;
+  cf* s = lds_c + c * Cg::CS;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x), v0 = tile * Cg::TC;
+  const int f = blockIdx.y;
+  {
+    HC fa[Cg::NL];
+    load_half_tile<N>(F + (size_t)f * F_stride, Wp, v0, tid, fa);
+    stage_half_tile<N>(lds_c, v0, nvalid, tid, fa);
+  }
+  __syncthreads();
+  fft_lds<N, -1, Cg::CE>(s, j, tw);
+  {
+    // the reference's chunks: contiguous 16 bytes per lane, served by L2 / the Infinity Cache (every frame re-reads
+    // them); the registers of the FFT are free here, so all of the thread's values are requested at once
+    const int gf = G_stride ? f : 0;
+    const h2* Gt = G + (size_t)gf * G_stride + (size_t)v0 * N;
+    const float sc = scale * gscale[(size_t)gf * gs_stride + tile];
+    HC g[Cg::NL];
+#pragma unroll
+    for (int m = 0; m < Cg::NL; ++m) g[m] = *reinterpret_cast<const HC*>(Gt + (size_t)(tid + m * Cg::NTH) * Cg::VW);
+#pragma unroll
+    for (int m = 0; m < Cg::NL; ++m) {
+      const int idx = tid + m * Cg::NTH;
+      const int u = idx / Cg::CPR, c0 = (idx % Cg::CPR) * Cg::VW;
+#pragma unroll
+      for (int h = 0; h < Cg::VW; ++h) {
+        const int at = (c0 + h) * Cg::CS + padi<Cg::CE>(u);
+        cf p = xpower(lds_c[at], from_h2((h2){g[m][2 * h], g[m][2 * h + 1]}), sc, normalize);
+        if (u == 0 && v0 + c0 + h == 0) p = mkc(0.f, 0.f);
         lds_c[at] = p;
       }
     }
-    __syncthreads();
-    fft_lds<N, +1, Gm::CE>(s, j, tw);
   }
-  if (!FUSED && mode == 1) {
-    // the reference spectrum's block: all of this thread's values are requested at once (one round trip
-    // to L2 instead of one per value; the FFT's registers are free here)
-    float4 gr[Gm::CE / 2];
+  __syncthreads();
+  fft_lds<N, +1, Cg::CE>(s, j, tw);
+  store_float_tile<N>(lds_c, Q + (size_t)f * Q_stride, Wp, v0, tid);
+}
+
+template <int N>
+__global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 2) void cols_fused_kernel(
+    const h2* __restrict__ F, long long F_stride, const h2* __restrict__ Gref, long long G_stride,
+    cf* __restrict__ Q, long long Q_stride, int Wp, int nvalid, const cf* __restrict__ tw, int normalize, float scale) {
+  using Cg = ColGeom<N>;
+  typedef typename HChunk<Cg::VW>::T HC;
+  extern __shared__ cf lds_c[];
+  const int tid = threadIdx.x;
+  const int c = tid / Cg::CNT, j = tid % Cg::CNT;
+  const unsigned frame = blockIdx.y;
+  const int v0 = xcd_remap(blockIdx.x, gridDim.x) * Cg::TC;
+  cf* const lds_g = lds_c + Cg::TC * Cg::CS;     // the reference's tile
+  {
+    HC w[Cg::NL];
+    load_half_tile<N>(F + (size_t)frame * F_stride, Wp, v0, tid, w);
+    stage_half_tile<N>(lds_c, v0, nvalid, tid, w);
+    load_half_tile<N>(Gref + (size_t)frame * G_stride, Wp, v0, tid, w);
+    stage_half_tile<N>(lds_g, v0, nvalid, tid, w);
+  }
+  __syncthreads();
+  fft_lds<N, -1, Cg::CE>(lds_c + c * Cg::CS, j, tw);
+  fft_lds<N, -1, Cg::CE>(lds_g + c * Cg::CS, j, tw);
 #pragma unroll
-    for (int m = 0; m < Gm::CE / 2; ++m)
-      gr[m] = *reinterpret_cast<const float4*>(Gref + (size_t)frame * G_stride + (size_t)v0 * N + 2 * (tid + m * NTH));   // tile-major: [u][cc]
+  for (int m = 0; m < Cg::NL; ++m) {
+    const int idx = tid + m * Cg::NTH;
+    const int u = idx / Cg::CPR, c0 = (idx % Cg::CPR) * Cg::VW;
 #pragma unroll
-    for (int m = 0; m < Gm::CE / 2; ++m) {
-      const int idx = tid + m * NTH;
-      const int pc = idx % HP, u = idx / HP;
-      const float4 f2 = gr[m];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const cf g = lds_c[(2 * pc + h) * Gm::CS + padi<Gm::CE>(u)];
-        const cf f = h ? mkc(f2.z, f2.w) : mkc(f2.x, f2.y);
-        cf p = mkc((f.x * g.x + f.y * g.y) * scale, (f.y * g.x - f.x * g.y) * scale);
-        if (normalize) {
-          float m2 = p.x * p.x + p.y * p.y;
-          float inv = m2 > 0.f ? rsqrtf(m2) : 0.f;
-          p.x *= inv;
-          p.y *= inv;
-        }
-        if (u == 0 && v0 + 2 * pc + h == 0) p = mkc(0.f, 0.f);
-        lds_c[(2 * pc + h) * Gm::CS + padi<Gm::CE>(u)] = p;
-      }
+    for (int h = 0; h < Cg::VW; ++h) {
+      const int at = (c0 + h) * Cg::CS + padi<Cg::CE>(u);
+      cf p = xpower(lds_c[at], lds_g[at], scale, normalize);
+      if (u == 0 && v0 + c0 + h == 0) p = mkc(0.f, 0.f);
+      lds_c[at] = p;
     }
-    __syncthreads();
-    fft_lds<N, +1, Gm::CE>(s, j, tw);
   }
-  if (!FUSED && mode == 0) {
-#pragma unroll 4
-    for (int m = 0; m < Gm::CE / 2; ++m) {
-      const int idx = tid + m * NTH;
-      const int pc = idx % HP, u = idx / HP;
-      const cf a = lds_c[(2 * pc) * Gm::CS + padi<Gm::CE>(u)], b2 = lds_c[(2 * pc + 1) * Gm::CS + padi<Gm::CE>(u)];
-      *reinterpret_cast<float4*>(R + (size_t)frame * R_stride + (size_t)v0 * N + 2 * idx) = make_float4(a.x, a.y, b2.x, b2.y);
-    }
-    return;
-  }
-#pragma unroll 4
-  for (int m = 0; m < Gm::CE / 2; ++m) {
-    const int idx = tid + m * NTH;
-    const int pc = idx % HP, u = idx / HP;
-    const cf a = lds_c[(2 * pc) * Gm::CS + padi<Gm::CE>(u)], b2 = lds_c[(2 * pc + 1) * Gm::CS + padi<Gm::CE>(u)];
-    *reinterpret_cast<float4*>(Ff + (size_t)u * Wp + v0 + 2 * pc) = make_float4(a.x, a.y, b2.x, b2.y);
-  }
+  __syncthreads();
+  fft_lds<N, +1, Cg::CE>(lds_c + c * Cg::CS, j, tw);
+  store_float_tile<N>(lds_c, Q + (size_t)frame * Q_stride, Wp, v0, tid);
 }
 
 // K3 ---------------------------------------------------------------------------------------
@@ -1278,6 +1415,9 @@ __global__ __launch_bounds__(256, AM_MIN_WAVES) void apply_shift_kernel(const ui
         uint16_t* o0 = po + (size_t)(oy + y0) * X + xa;
 #pragma unroll
         for (int k = 0; k < AM_G; ++k) {   // clamp, then truncation toward zero; written once, not re-read here
+#ifdef AP_X_NOSTORE
+          if (res[k].x != 1.2345e-30f) continue;
+#endif
           __builtin_nontemporal_store((uint16_t)(unsigned)__builtin_amdgcn_fmed3f(res[k].x, 0.f, 65535.f), o0 + (size_t)k * X);
           __builtin_nontemporal_store((uint16_t)(unsigned)__builtin_amdgcn_fmed3f(res[k].y, 0.f, 65535.f), o0 + (size_t)k * X + 32);
         }
@@ -1359,7 +1499,11 @@ static bool make_plan(int Y, int X, RegPlan& p) {
 }
 
 struct RegWs {
-  cf *tw_x, *tw_y, *refspec, *F;
+  cf *tw_x, *tw_y;
+  h2* refspec;     // the reference's full spectrum: half pairs, tile-major chunks (cols_ref_kernel)
+  float* gscale;   // ... and the factor per tile that undoes its scale
+  h2* F;           // row spectra of the batch's moving planes, half pairs
+  cf* Q;           // float: the batch's Q[y][v]; its slots also take the float row spectra on their way to cols_ref
   float* pval;
   int* pidx;
   int2* coarse;
@@ -1374,11 +1518,11 @@ struct RegWs {
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 static size_t reg_fixed_bytes(const RegPlan& p) {
-  return align256(4096 * 8) * 2 + align256(p.spec * 8) + align256((size_t)p.Y * p.X * 2) +
-         align256((size_t)p.Y * p.X * 4) + 1024;
+  return align256(4096 * 8) * 2 + align256(p.spec * 4) + align256((size_t)p.col_blocks * 4) +
+         align256((size_t)p.Y * p.X * 2) + align256((size_t)p.Y * p.X * 4) + 1024;
 }
 static size_t reg_frame_bytes(const RegPlan& p, int Z) {
-  size_t b = align256(p.spec * 8) + 2 * align256((size_t)p.row_blocks * 4) + 256 +
+  size_t b = align256(p.spec * 4) + align256(p.spec * 8) + 2 * align256((size_t)p.row_blocks * 4) + 256 +
              align256((size_t)p.ncg * p.nuc * UP_NV * 4) + align256((size_t)p.Py * UP_YS * 4) +
              align256((size_t)p.Wp * UP_XS * 4) + align256((size_t)((p.Py + 255) / 256) * UP_NQ * 4);
   if (Z > 1) b += align256((size_t)p.Y * p.X * 2);
@@ -1399,10 +1543,12 @@ static bool carve(void* ws, size_t bytes, const RegPlan& p, int Z, RegWs& w) {
   };
   w.tw_x = (cf*)take(4096 * 8);
   w.tw_y = (cf*)take(4096 * 8);
-  w.refspec = (cf*)take(p.spec * 8);
+  w.refspec = (h2*)take(p.spec * 4);
+  w.gscale = (float*)take((size_t)p.col_blocks * 4);
   w.mip_ref = (uint16_t*)take((size_t)p.Y * p.X * 2);
   w.sum = (uint32_t*)take((size_t)p.Y * p.X * 4);
-  w.F = (cf*)take((size_t)batch * align256(p.spec * 8));
+  w.F = (h2*)take((size_t)batch * align256(p.spec * 4));
+  w.Q = (cf*)take((size_t)batch * align256(p.spec * 8));
   w.pval = (float*)take((size_t)batch * p.row_blocks * 4);
   w.pidx = (int*)take((size_t)batch * p.row_blocks * 4);
   w.coarse = (int2*)take((size_t)batch * 8);
@@ -1439,36 +1585,78 @@ struct PlaneSub {
   long long stride = 0;
 };
 
+// half16: the row spectra go out as packed half pairs (moving planes; F_stride in half pairs), else as float
+// (the reference plane on its way to cols_ref_kernel; F_stride in float pairs)
 static int launch_rows_r2c(const RegPlan& p, const void* src, int kind, long long plane_stride, float in_scale,
-                           cf* F, long long F_stride, int n, const cf* tw_x, hipStream_t st, PlaneSub sub = {}) {
+                           void* F, long long F_stride, bool half16, int n, const cf* tw_x, hipStream_t st,
+                           PlaneSub sub = {}) {
   const int vec = kind == 0 && aligned16(src) && p.X % 8 == 0 && p.ox % 8 == 0 && plane_stride % 8 == 0;
   IAP_FOR_N(p.Px, {
     using Gm = FftGeom<N>;
     size_t lds = (size_t)Gm::G * Gm::PADN * sizeof(cf);
-    IAP_HIP(allow_lds(rows_r2c_kernel<N>, lds));
-    { ProfScope ps_(K_ROWS_R2C, st); hipLaunchKernelGGL(rows_r2c_kernel<N>, dim3(p.row_blocks, n), dim3(Gm::G * Gm::NT), lds, st, src, kind,
-                       plane_stride, p.X, p.oy, p.ox, in_scale, F, F_stride, p.Wp, tw_x, vec, sub.sub2, sub.stride); }
+    ProfScope ps_(K_ROWS_R2C, st);
+    if (half16) {
+      IAP_HIP(allow_lds((rows_r2c_kernel<N, true>), lds));
+      hipLaunchKernelGGL((rows_r2c_kernel<N, true>), dim3(p.row_blocks, n), dim3(Gm::G * Gm::NT), lds, st, src, kind,
+                         plane_stride, p.X, p.oy, p.ox, in_scale, F, F_stride, p.Wp, tw_x, vec, sub.sub2, sub.stride);
+    } else {
+      IAP_HIP(allow_lds((rows_r2c_kernel<N, false>), lds));
+      hipLaunchKernelGGL((rows_r2c_kernel<N, false>), dim3(p.row_blocks, n), dim3(Gm::G * Gm::NT), lds, st, src, kind,
+                         plane_stride, p.X, p.oy, p.ox, in_scale, F, F_stride, p.Wp, tw_x, vec, sub.sub2, sub.stride);
+    }
   });
   IAP_LAUNCH_CHECK();
   return IAP_OK;
 }
 
-static int launch_cols(const RegPlan& p, cf* F, long long F_stride, const cf* Gref, long long G_stride, cf* R,
-                       long long R_stride, int n, const cf* tw_y, int mode, int normalize, hipStream_t st) {
-  float scale = 1.0f / ((float)p.Py * (float)p.Px);
+static long long spec16_stride(const RegPlan& p) { return (long long)(align256(p.spec * 4) / 4); }   // half pairs
+static long long spec32_stride(const RegPlan& p) { return (long long)(align256(p.spec * 8) / 8); }   // float pairs
+static int valid_tiles(const RegPlan& p) { return (p.Px / 2 + 1 + geom_TC(p.Py) - 1) / geom_TC(p.Py); }
+
+// n references: float row spectra F -> column FFT -> G (half pairs, tile-major chunks) + gscale per tile
+static int launch_cols_ref(const RegPlan& p, const cf* F, long long F_stride, h2* G, long long G_stride, float* gscale,
+                           int n, const cf* tw_y, hipStream_t st) {
   IAP_FOR_N(p.Py, {
     using Gm = FftGeom<N>;
-    size_t lds = (size_t)Gm::TC * Gm::CS * sizeof(cf) * (mode == 2 ? 2 : 1);
+    size_t lds = (size_t)Gm::TC * Gm::CS * sizeof(cf);
+    IAP_HIP(allow_lds(cols_ref_kernel<N>, lds));
     ProfScope ps_(K_COLS, st);
-    if (mode == 2) {
-      IAP_HIP(allow_lds(cols_kernel<N, true>, lds));
-      hipLaunchKernelGGL((cols_kernel<N, true>), dim3(p.col_blocks, n), dim3(Gm::TC * Gm::CNT), lds, st, F, F_stride, Gref,
-                         G_stride, R, R_stride, p.Wp, tw_y, mode, normalize, scale);
-    } else {
-      IAP_HIP(allow_lds(cols_kernel<N, false>, lds));
-      hipLaunchKernelGGL((cols_kernel<N, false>), dim3(p.col_blocks, n), dim3(Gm::TC * Gm::CNT), lds, st, F, F_stride, Gref,
-                         G_stride, R, R_stride, p.Wp, tw_y, mode, normalize, scale);
-    }
+    hipLaunchKernelGGL(cols_ref_kernel<N>, dim3(valid_tiles(p), n), dim3(Gm::TC * Gm::CNT), lds, st, F, F_stride, G,
+                       G_stride, gscale, p.col_blocks, p.Wp, p.Px / 2 + 1, tw_y);
+  });
+  IAP_LAUNCH_CHECK();
+  return IAP_OK;
+}
+
+// n moving frames (half row spectra F) against G (one for all: G_stride 0, or one per frame) -> Q (float)
+static int launch_cols_xpower(const RegPlan& p, const h2* F, const h2* G, long long G_stride, const float* gscale,
+                              cf* Q, int n, const cf* tw_y, int normalize, hipStream_t st) {
+  // F holds F_true * 0.5 / Px (fs16), G holds G_true / gscale: P = G conj(F) / (Py Px) needs 2 Px / (Py Px)
+  const float scale = 2.0f / (float)p.Py;
+  IAP_FOR_N(p.Py, {
+    using Gm = FftGeom<N>;
+    size_t lds = (size_t)Gm::TC * Gm::CS * sizeof(cf);
+    IAP_HIP(allow_lds(cols_xpower_kernel<N>, lds));
+    ProfScope ps_(K_COLS, st);
+    hipLaunchKernelGGL(cols_xpower_kernel<N>, dim3(valid_tiles(p), n), dim3(Gm::TC * Gm::CNT), lds, st, F,
+                       spec16_stride(p), G, G_stride, gscale, p.col_blocks, Q, spec32_stride(p), p.Wp, p.Px / 2 + 1,
+                       tw_y, normalize, scale);
+  });
+  IAP_LAUNCH_CHECK();
+  return IAP_OK;
+}
+
+// n moving frames (half row spectra F) against half ROW spectra of their references (G_stride 0: one for all)
+static int launch_cols_fused(const RegPlan& p, const h2* F, const h2* Grows, long long G_stride, cf* Q, int n,
+                             const cf* tw_y, int normalize, hipStream_t st) {
+  const float scale = 4.0f * (float)p.Px / (float)p.Py;   // both factors carry fs16 = 0.5 / Px
+  IAP_FOR_N(p.Py, {
+    using Gm = FftGeom<N>;
+    size_t lds = (size_t)Gm::TC * Gm::CS * sizeof(cf) * 2;
+    IAP_HIP(allow_lds(cols_fused_kernel<N>, lds));
+    ProfScope ps_(K_COLS, st);
+    hipLaunchKernelGGL(cols_fused_kernel<N>, dim3(valid_tiles(p), n), dim3(Gm::TC * Gm::CNT), lds, st, F, spec16_stride(p),
+                       Grows, G_stride, Q, spec32_stride(p), p.Wp, p.Px / 2 + 1, tw_y, normalize, scale);
   });
   IAP_LAUNCH_CHECK();
   return IAP_OK;
@@ -1494,16 +1682,15 @@ static int reg_init_tables(const RegPlan& p, RegWs& w, hipStream_t st) {
   return IAP_OK;
 }
 
-// full 2-D spectrum of the reference plane into w.refspec (tile-major, see cols_kernel); the row
-// pass goes through the first frame slot of w.F, which is free between batches
+// full 2-D spectrum of the reference plane into w.refspec / w.gscale; the float row pass goes through the
+// first frame slot of w.Q, which is free between batches
 static int reg_ref_spectrum(const RegPlan& p, RegWs& w, const void* ref, int kind, float in_scale, hipStream_t st,
                             PlaneSub sub = {}) {
-  int rc = launch_rows_r2c(p, ref, kind, 0, in_scale, w.F, 0, 1, w.tw_x, st, sub);
+  int rc = launch_rows_r2c(p, ref, kind, 0, in_scale, w.Q, 0, false, 1, w.tw_x, st, sub);
   if (rc) return rc;
-  return launch_cols(p, w.F, 0, nullptr, 0, w.refspec, 0, 1, w.tw_y, 0, 0, st);
+  return launch_cols_ref(p, w.Q, 0, w.refspec, 0, w.gscale, 1, w.tw_y, st);
 }
 
-// shifts for n moving planes (n <= w.batch) against w.refspec
 // Workgroups of upsample_partial_kernel the current device holds at once.
 static int upsample_capacity() {
   static int cap[64] = {0};
@@ -1520,20 +1707,31 @@ static int upsample_capacity() {
   return cap[dev];
 }
 
+// The reference of an estimate: w.refspec (default), one spectrum per frame (gref/gscale, channel-shift pairs), or
+// the half ROW spectrum of one reference plane (ref_rows: the serial 'previous' chain, cols_fused_kernel).
+struct RegRef {
+  const h2* gref = nullptr;
+  long long g_stride = 0;
+  const float* gscale = nullptr;
+  const h2* ref_rows = nullptr;
+};
+
+// shifts for n moving planes (n <= w.batch)
 static int reg_estimate_batch(const RegPlan& p, RegWs& w, const uint16_t* mov, long long mov_stride, int n, int flags,
-                              double* shifts, hipStream_t st, const cf* gref = nullptr, long long g_stride = 0,
-                              cf* rows = nullptr, const cf* ref_rows = nullptr, PlaneSub msub = {}) {
+                              double* shifts, hipStream_t st, RegRef ref = {}, const h2* rows = nullptr,
+                              PlaneSub msub = {}) {
   // rows != nullptr: the n row-pass spectra are already there (slots of w.F filled ahead of a serial loop)
-  // ref_rows != nullptr: the reference comes as its row-pass spectrum (cols_kernel mode 2), not as w.refspec
-  const long long fs = (long long)(align256(p.spec * 8) / 8);
+  const long long fs = spec32_stride(p);
   const bool up = flags & IAP_REG_UPSAMPLE;
-  cf* F = rows ? rows : w.F;
-  int rc = rows ? IAP_OK : launch_rows_r2c(p, mov, 0, mov_stride, 1.0f, F, fs, n, w.tw_x, st, msub);
+  const int normalize = (flags & IAP_REG_NORMALIZE) ? 1 : 0;
+  const h2* F16 = rows ? rows : w.F;
+  int rc = rows ? IAP_OK : launch_rows_r2c(p, mov, 0, mov_stride, 1.0f, w.F, spec16_stride(p), true, n, w.tw_x, st, msub);
   if (rc) return rc;
-  rc = ref_rows ? launch_cols(p, F, fs, ref_rows, 0, nullptr, 0, n, w.tw_y, 2, (flags & IAP_REG_NORMALIZE) ? 1 : 0, st)
-                : launch_cols(p, F, fs, gref ? gref : w.refspec, g_stride, nullptr, 0, n, w.tw_y, 1,
-                              (flags & IAP_REG_NORMALIZE) ? 1 : 0, st);
+  if (ref.ref_rows) rc = launch_cols_fused(p, F16, ref.ref_rows, 0, w.Q, n, w.tw_y, normalize, st);
+  else if (ref.gref) rc = launch_cols_xpower(p, F16, ref.gref, ref.g_stride, ref.gscale, w.Q, n, w.tw_y, normalize, st);
+  else rc = launch_cols_xpower(p, F16, w.refspec, 0, w.gscale, w.Q, n, w.tw_y, normalize, st);
   if (rc) return rc;
+  const cf* F = w.Q;
   rc = launch_rows_c2r(p, F, fs, n, w.tw_x, w.pval, w.pidx, st);
   if (rc) return rc;
   if (!up) {
@@ -1677,11 +1875,14 @@ extern "C" int iap_reg_estimate_u16(const void* ref, int ref_kind, const uint16_
 // Pairwise estimate (channel shift, utility.py:313-330: every plane against the same frame's plane of the
 // registration channel): the workspace is that of the plain estimate plus one reference spectrum per
 // frame of the batch.
+// one reference spectrum (half pairs) and its per-tile scales per frame of the batch
+static size_t pair_ref_bytes(const RegPlan& p) { return align256(p.spec * 4) + align256((size_t)p.col_blocks * 4); }
+
 extern "C" size_t iap_reg_pairs_ws_bytes(int Y, int X, int batch) {
   RegPlan p;
   if (!make_plan(Y, X, p)) return 0;
   if (batch < 1) batch = 1;
-  return reg_fixed_bytes(p) + (size_t)batch * (reg_frame_bytes(p, 1) + align256(p.spec * 8)) + 512;
+  return reg_fixed_bytes(p) + (size_t)batch * (reg_frame_bytes(p, 1) + pair_ref_bytes(p)) + 512;
 }
 
 extern "C" int iap_reg_estimate_pairs_u16(const uint16_t* ref, int64_t ref_stride, const uint16_t* mov,
@@ -1694,30 +1895,35 @@ extern "C" int iap_reg_estimate_pairs_u16(const uint16_t* ref, int64_t ref_strid
   RegPlan p;
   int rc = reg_check("iap_reg_estimate_pairs_u16", Y, X, p);
   if (rc) return rc;
-  // split the workspace: per-frame spectra first, the plain estimate's layout in the rest
-  const size_t gs = align256(p.spec * 8), per = reg_frame_bytes(p, 1) + gs, fixed = reg_fixed_bytes(p);
+  // split the workspace: per-frame reference spectra and their scales first, the plain estimate's layout in the rest
+  const size_t gs = align256(p.spec * 4), ss = align256((size_t)p.col_blocks * 4), per = reg_frame_bytes(p, 1) + gs + ss,
+               fixed = reg_fixed_bytes(p);
   IAP_REQUIRE(ws_bytes >= fixed + per + 512, IAP_E_WS, "iap_reg_estimate_pairs_u16: workspace of %zu bytes, need %zu",
               ws_bytes, iap_reg_pairs_ws_bytes(Y, X, 1));
   int batch = (int)((ws_bytes - fixed - 512) / per);
   if (batch > 4096) batch = 4096;
   char* base = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-  cf* gref = (cf*)base;
+  h2* gref = (h2*)base;
+  float* gscale = (float*)(base + (size_t)batch * gs);
   RegWs w;
-  IAP_REQUIRE(carve(base + (size_t)batch * gs, fixed + (size_t)batch * reg_frame_bytes(p, 1) + 256, p, 1, w) && w.batch >= 1,
+  IAP_REQUIRE(carve(base + (size_t)batch * (gs + ss), fixed + (size_t)batch * reg_frame_bytes(p, 1) + 256, p, 1, w) && w.batch >= 1,
               IAP_E_WS, "iap_reg_estimate_pairs_u16: workspace too small");
   if (w.batch > batch) w.batch = batch;
   hipStream_t st = as_stream(stream);
   rc = reg_init_tables(p, w, st);
   if (rc) return rc;
-  const long long fs = (long long)(align256(p.spec * 8) / 8), g_stride = (long long)(gs / 8);
+  RegRef rr;
+  rr.gref = gref;
+  rr.g_stride = (long long)(gs / 4);
+  rr.gscale = gscale;
   for (int64_t f0 = 0; f0 < n; f0 += w.batch) {
     const int nb = (int)(n - f0 < w.batch ? n - f0 : w.batch);
-    // reference planes -> row spectra in F -> full spectra, one per frame
-    rc = launch_rows_r2c(p, ref + f0 * ref_stride, 0, ref_stride, 1.0f, w.F, fs, nb, w.tw_x, st);
+    // reference planes -> float row spectra in the Q slots -> full spectra (half pairs), one per frame
+    rc = launch_rows_r2c(p, ref + f0 * ref_stride, 0, ref_stride, 1.0f, w.Q, spec32_stride(p), false, nb, w.tw_x, st);
     if (rc) return rc;
-    rc = launch_cols(p, w.F, fs, nullptr, 0, gref, g_stride, nb, w.tw_y, 0, 0, st);
+    rc = launch_cols_ref(p, w.Q, spec32_stride(p), gref, rr.g_stride, gscale, nb, w.tw_y, st);
     if (rc) return rc;
-    rc = reg_estimate_batch(p, w, mov + f0 * mov_stride, mov_stride, nb, flags, shifts_out + 2 * f0, st, gref, g_stride);
+    rc = reg_estimate_batch(p, w, mov + f0 * mov_stride, mov_stride, nb, flags, shifts_out + 2 * f0, st, rr);
     if (rc) return rc;
   }
   return IAP_OK;
@@ -1797,7 +2003,7 @@ static int im_reg_impl(const uint16_t* in, uint16_t* out, int64_t T, int C, int 
     }
     // The chain reference -> estimate -> warp is serial in time, the row pass over the raw moving planes is
     // not: it runs ahead, one launch per group of frames, into slots 1.. of w.F (slot 0 is the reference's).
-    const long long fs = (long long)(align256(p.spec * 8) / 8);
+    const long long fs = spec16_stride(p);
     const int ahead = w.batch - 1;
     for (long long f0 = 1; f0 < T; f0 += std::max(ahead, 1)) {
       const int nb = (int)std::min<long long>(std::max(ahead, 1), T - f0);
@@ -1807,7 +2013,7 @@ static int im_reg_impl(const uint16_t* in, uint16_t* out, int64_t T, int C, int 
       rc = mov_planes(in, f0, nb, mp, ms, msub);
       if (rc) return rc;
       if (ahead) {
-        rc = launch_rows_r2c(p, mp, 0, ms, 1.0f, w.F + fs, fs, nb, w.tw_x, st, msub);
+        rc = launch_rows_r2c(p, mp, 0, ms, 1.0f, w.F + fs, fs, true, nb, w.tw_x, st, msub);
         if (rc) return rc;
       }
       for (int k = 0; k < nb; ++k) {
@@ -1821,14 +2027,17 @@ static int im_reg_impl(const uint16_t* in, uint16_t* out, int64_t T, int C, int 
           refp = w.mip_ref;
         }
         if (ahead) {   // the reference's row pass into slot 0; its column FFT rides in the cross-power launch
-          rc = launch_rows_r2c(p, refp, 0, 0, 1.0f, w.F, 0, 1, w.tw_x, st);
+          rc = launch_rows_r2c(p, refp, 0, 0, 1.0f, w.F, 0, true, 1, w.tw_x, st);
           if (rc) return rc;
-          rc = reg_estimate_batch(p, w, mp, ms, 1, flags, shifts_out + 2 * f, st, nullptr, 0,
-                                  w.F + (size_t)(k + 1) * fs, w.F);
-        } else {
-          rc = reg_ref_spectrum(p, w, refp, 0, 1.0f, st);
+          RegRef rr;
+          rr.ref_rows = w.F;
+          rc = reg_estimate_batch(p, w, mp, ms, 1, flags, shifts_out + 2 * f, st, rr, w.F + (size_t)(k + 1) * fs);
+        } else {   // a one-frame workspace: the same arithmetic, the reference's row spectrum in w.refspec's place
+          rc = launch_rows_r2c(p, refp, 0, 0, 1.0f, w.refspec, 0, true, 1, w.tw_x, st);
           if (rc) return rc;
-          rc = reg_estimate_batch(p, w, mp, ms, 1, flags, shifts_out + 2 * f, st, nullptr, 0, nullptr, nullptr, msub);
+          RegRef rr;
+          rr.ref_rows = w.refspec;
+          rc = reg_estimate_batch(p, w, mp, ms, 1, flags, shifts_out + 2 * f, st, rr, nullptr, msub);
         }
         if (rc) return rc;
         rc = launch_apply(in + f * frame_stride, out + f * frame_stride, 1, ppf, Y, X, shifts_out + 2 * f, st,
@@ -1877,7 +2086,7 @@ static int im_reg_impl(const uint16_t* in, uint16_t* out, int64_t T, int C, int 
     PlaneSub msub;
     rc = mov_planes(in, f0, nb, mp, ms, msub);
     if (rc) return rc;
-    rc = reg_estimate_batch(p, w, mp, ms, nb, flags, shifts_out + 2 * f0, st, nullptr, 0, nullptr, nullptr, msub);
+    rc = reg_estimate_batch(p, w, mp, ms, nb, flags, shifts_out + 2 * f0, st, RegRef{}, nullptr, msub);
     if (rc) return rc;
   }
   // 'first': frame 0 is the reference itself, its shift is zero by definition (the estimate, summed in f32
