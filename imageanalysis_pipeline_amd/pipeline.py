@@ -23,7 +23,7 @@ import pandas as pd
 import torch
 
 from . import ops
-from .tiffio import imread, imwrite, read_planes, write_planes
+from .tiffio import imread, imwrite, read_planes, read_planes_to_device, write_planes, write_planes_from_device
 
 
 def _device():
@@ -44,6 +44,20 @@ def _read_u16_planes(paths):
 
 def _write_u16_planes(paths, planes):
     write_planes(paths, np.ascontiguousarray(planes, dtype=np.uint16))
+
+
+def _planes_to_device(paths, dev):
+    """n plane files -> device u16 (n, Y, X): file reads into pinned blocks overlapped with their upload
+    (tiffio.read_planes_to_device); files the batched reader does not take go through the generic one."""
+    try:
+        return read_planes_to_device(paths, dev)
+    except ValueError:
+        return ops.to_device_u16(np.stack([imread(p) for p in paths]).astype(np.uint16), dev)
+
+
+def _planes_from_device(paths, planes):
+    """device u16 planes (any leading shape, one path per plane) -> files, downloads overlapped with the writes"""
+    write_planes_from_device(paths, planes.reshape(-1, *planes.shape[-2:]))
 
 
 class Utility:
@@ -155,8 +169,9 @@ class Utility:
                 imwrite(join(sep, save_dir + sep, name), plane.astype(np.uint16))
 
     @staticmethod
-    def _read_folder_stack(fold_path, exp_para, prefix_of=lambda c: c, channels=None):
-        """Whole folder -> u16 (T, C, Z, Y, X) host array (planar, the on-disk layout)."""
+    def _read_folder_stack(fold_path, exp_para, prefix_of=lambda c: c, channels=None, dev=None):
+        """Whole folder -> u16 (T, C, Z, Y, X) (planar, the on-disk layout): a host array, or with ``dev`` a device
+        tensor filled through pinned staging blocks while the next block is still being read."""
         chans = channels if channels is not None else exp_para["channel_list"]
         t, z = exp_para["t"], exp_para["z"]
         idx = Utility._folder_index(fold_path)
@@ -168,15 +183,22 @@ class Utility:
                     if name is None:
                         raise FileNotFoundError(f"{fold_path}: missing plane {prefix_of(chan)} f={f + 1} z={k + 1}")
                     paths.append(join(sep, fold_path + sep, name))
-        planes = _read_u16_planes(paths)
+        if dev is not None:
+            planes = _planes_to_device(paths, dev)
+        else:
+            planes = _read_u16_planes(paths)
         return planes.reshape(t, len(chans), z, *planes.shape[1:])
 
     @staticmethod
     def _write_folder_stack(fold_path, stack, channels):
+        """(T, C, Z, Y, X) u16, host array or device tensor -> one file per plane"""
         t, c, z = stack.shape[:3]
         paths = [join(sep, fold_path + sep, Utility._plane_name(chan, f, k))
                  for f in range(t) for chan in channels for k in range(z)]
-        _write_u16_planes(paths, np.asarray(stack).reshape(t * c * z, *stack.shape[3:]))
+        if isinstance(stack, torch.Tensor) and stack.is_cuda:
+            _planes_from_device(paths, stack)
+        else:
+            _write_u16_planes(paths, np.asarray(stack).reshape(t * c * z, *stack.shape[3:]))
 
     # ------------------------------------------------------------------ background (utility.py:175-270)
     @staticmethod
@@ -190,11 +212,10 @@ class Utility:
         names = [f for f in sorted(listdir(imgFold_path)) if f.endswith(".tif")]
         if names:
             paths = [join(sep, imgFold_path + sep, f) for f in names]
-            planes = _read_u16_planes(paths)
-            thr = ops.smo_threshold(planes.shape[-2:], sigma=sigma, size=size, seed=seed, device=dev)
-            d = ops.to_device_u16(planes, dev)
+            d = _planes_to_device(paths, dev)
+            thr = ops.smo_threshold(tuple(d.shape[-2:]), sigma=sigma, size=size, seed=seed, device=dev)
             out, _, _ = ops.bg_smo(d, thr, sigma=sigma, size=size, out=d)     # in place, as the reference
-            _write_u16_planes(paths, ops.to_numpy_u16(out))
+            _planes_from_device(paths, out)
         exp_prop["fct_inputs"]["smo_bg_sub"] = {"imgFold_path": imgFold_path, "smo_sigma": sigma, "smo_size": size}
         exp_prop["img_preProcess"]["bg_sub"] = "Auto"
         Utility.save_exp_prop(exp_path=exp_path, exp_prop=exp_prop)
@@ -213,9 +234,9 @@ class Utility:
             r0, r1 = sorted((int(r0), int(r1)))
             c0, c1 = sorted((int(c0), int(c1)))
             dev = _device()
-            stack = Utility._read_folder_stack(imgFold_path, exp_para)
-            out, _ = ops.bg_manual(ops.to_device_u16(stack, dev), (r0, c0, r1, c1))
-            Utility._write_folder_stack(imgFold_path, ops.to_numpy_u16(out), exp_para["channel_list"])
+            stack = Utility._read_folder_stack(imgFold_path, exp_para, dev=dev)
+            out, _ = ops.bg_manual(stack, (r0, c0, r1, c1))
+            Utility._write_folder_stack(imgFold_path, out, exp_para["channel_list"])
             exp_prop["fct_inputs"]["man_bg_sub"] = {"imgFold_path": imgFold_path}
             exp_prop["img_preProcess"]["bg_sub"] = "Manual"
             Utility.save_exp_prop(exp_path=exp_path, exp_prop=exp_prop)
@@ -253,9 +274,9 @@ class Utility:
                 # effect on the output; it is therefore not run here.
                 chans = exp_para["channel_list"]
                 dev = _device()
-                stack = Utility._read_folder_stack(imgFold_path, exp_para)
-                out, shifts = ops.im_reg(ops.to_device_u16(stack, dev), chans.index(reg_channel), reg_ref)
-                Utility._write_folder_stack(reg_im_path, ops.to_numpy_u16(out), chans)
+                stack = Utility._read_folder_stack(imgFold_path, exp_para, dev=dev)
+                out, shifts = ops.im_reg(stack, chans.index(reg_channel), reg_ref)
+                Utility._write_folder_stack(reg_im_path, out, chans)
                 exp_prop["fct_inputs"]["im_reg"] = {"imgFold_path": imgFold_path, "reg_channel": reg_channel,
                                                     "reg_mtd": reg_mtd, "reg_ref": reg_ref, "reg_ow": reg_ow}
                 if "channel_seg" in exp_prop:
@@ -288,9 +309,9 @@ class Utility:
             names = [f for f in sorted(listdir(imgFold_path)) if f.endswith(".tif")]
             if names:
                 dev = _device()
-                planes = _read_u16_planes([join(sep, imgFold_path + sep, f) for f in names])
-                res = ops.to_numpy_u16(ops.gauss_blur(ops.to_device_u16(planes, dev), blur_kernel, blur_sigma))
-                _write_u16_planes([join(sep, blur_img_path + sep, f) for f in names], res)
+                planes = _planes_to_device([join(sep, imgFold_path + sep, f) for f in names], dev)
+                _planes_from_device([join(sep, blur_img_path + sep, f) for f in names],
+                                    ops.gauss_blur(planes, blur_kernel, blur_sigma))
             exp_prop["fct_inputs"]["blur_img"] = {"imgFold_path": imgFold_path, "blur_kernel": blur_kernel,
                                                   "blur_sigma": blur_sigma, "blur_ow": blur_ow}
             exp_prop["img_preProcess"]["blur"] = True
@@ -502,12 +523,13 @@ class Analysis(Utility):
         if not any(chan in file for file in listdir(folder)):
             raise AttributeError(f"No masks was found for the selected segmented channel: {chan}")
         return Utility._read_folder_stack(folder, self.exp_prop["metadata"], prefix_of=lambda c: prefix,
-                                          channels=[chan])[:, 0]
+                                          channels=[chan], dev=_device())[:, 0].contiguous()
 
     def _measure(self, img_stack, lab_stack):
         dev = _device()
-        img = ops.to_device_u16(img_stack, dev) if img_stack is not None else None
-        lab = ops.to_device_u16(lab_stack, dev)
+        as_dev = lambda a: a if isinstance(a, torch.Tensor) else ops.to_device_u16(a, dev)   # noqa: E731
+        img = as_dev(img_stack) if img_stack is not None else None
+        lab = as_dev(lab_stack)
         if img is None:  # centroids only: a zero image channel keeps one code path
             img = torch.zeros((lab.shape[0], 1) + tuple(lab.shape[1:]), dtype=torch.uint16, device=dev)
         return ops.measure_labels(img, lab)
@@ -531,7 +553,8 @@ class Analysis(Utility):
                 neg_lst = self.exp_prop["masks_process"]["classification"]["neg"]
                 keys += ["cell_class", "pos_cell"]
             exp_name = self._exp_name()
-            img_stack = Utility._read_folder_stack(join(sep, self.exp_path + sep, imgFold), self.exp_prop["metadata"])
+            img_stack = Utility._read_folder_stack(join(sep, self.exp_path + sep, imgFold), self.exp_prop["metadata"],
+                                                   dev=_device())
             df = pd.DataFrame()
             by_chan = {}
             for folder, chan, shape in sets:
@@ -632,7 +655,7 @@ class Analysis(Utility):
                                  "maximum projection, analysis.py:281-282)")
             masks = masks.reshape(t, *masks.shape[-2:])
             exp_para = self.exp_prop["metadata"]
-            stack = ops.to_device_u16(Utility._read_folder_stack(img_path, exp_para), dev)      # (T, C, Z, Y, X)
+            stack = Utility._read_folder_stack(img_path, exp_para, dev=dev)                       # (T, C, Z, Y, X)
             if self.z_size > 1:                                                                   # np.amax over z
                 img = torch.stack([ops.mip(stack[:, c]) for c in range(stack.shape[1])], 1)
             else:

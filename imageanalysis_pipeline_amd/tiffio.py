@@ -5,7 +5,8 @@ single-page, uncompressed, 16-bit (or 8/32-bit) grayscale, as written by
 ``imread`` / ``imwrite`` are the single-plane calls of the reference (tifffile when importable, a
 pure-Python baseline reader otherwise).  ``read_planes`` / ``write_planes`` are the batched native
 path (csrc/tiffio.hip): a thread pool moves whole plane sequences between files
-and one pinned host buffer, which load_stack then copies to the GPU in one async transfer.
+and one host buffer.  ``read_planes_to_device`` / ``write_planes_from_device`` are what the shim's folder calls
+use: two pinned staging buffers, the file I/O of block k + 1 overlapped with the PCIe copy of block k.
 """
 from __future__ import annotations
 
@@ -75,6 +76,114 @@ def write_planes(paths, planes, threads: int | None = None) -> None:
         raise ValueError("write_planes: planes must be (n, Y, X) with one path per plane")
     _lib.check(_lib.load().iap_tiff_write_u16(_path_array(paths), len(paths), a.ctypes.data, a.shape[1], a.shape[2],
                                               threads or IO_THREADS), "iap_tiff_write_u16")
+
+
+STAGE_BYTES = 256 << 20      # one pinned staging buffer (two are in use): a block of planes read / written at a time
+
+
+def _blocks(n, y, x, block_planes):
+    if not block_planes:
+        block_planes = max(1, STAGE_BYTES // (2 * y * x))
+    return [(i, min(n, i + block_planes)) for i in range(0, n, block_planes)]
+
+
+def read_planes_to_device(paths, device, shape=None, threads: int | None = None, block_planes: int | None = None):
+    """n plane files -> device tensor u16 (n, Y, X), staged through two pinned host buffers: a reader thread fills
+    block k + 1 (the native reader runs outside the GIL) while block k goes to the GPU with a non-blocking copy on
+    a side stream -- the loop of utility.py:487-524 (imread per file, np.stack, then one synchronous upload) with
+    file reads and the PCIe copy overlapped.  Raises ValueError as read_planes does for files it cannot take."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    paths = list(paths)
+    if not paths:
+        raise ValueError("read_planes_to_device: no files")
+    y, x = shape if shape is not None else probe(paths[0])[:2]
+    n = len(paths)
+    out = torch.empty((n, y, x), dtype=torch.uint16, device=device)
+    blocks = _blocks(n, y, x, block_planes)
+    nb = max(b - a for a, b in blocks)
+    stage = [torch.empty((nb, y, x), dtype=torch.uint16, pin_memory=True) for _ in range(min(2, len(blocks)))]
+    free = [None] * len(stage)                     # event after which a staging buffer may be overwritten
+    side = torch.cuda.Stream(device=device)
+    lib_threads = threads or IO_THREADS
+
+    def fill(k):
+        a, b = blocks[k]
+        buf = stage[k % len(stage)]
+        if free[k % len(stage)] is not None:
+            free[k % len(stage)].synchronize()     # its previous upload has left the buffer
+        from . import _lib
+        _lib.check(_lib.load().iap_tiff_read_u16(_path_array(paths[a:b]), b - a, buf.data_ptr(), y, x, lib_threads),
+                   "iap_tiff_read_u16")
+        return buf
+
+    with ThreadPoolExecutor(1) as pool:
+        pending = pool.submit(fill, 0)
+        for k, (a, b) in enumerate(blocks):
+            buf = pending.result()
+            if k + 1 < len(blocks):
+                pending = pool.submit(fill, k + 1)
+            with torch.cuda.stream(side):
+                out[a:b].copy_(buf[: b - a], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            free[k % len(stage)] = ev
+    torch.cuda.current_stream(device).wait_stream(side)
+    for ev in free:                                 # the pinned buffers go away with this call
+        if ev is not None:
+            ev.synchronize()
+    return out
+
+
+def write_planes_from_device(paths, planes, threads: int | None = None, block_planes: int | None = None) -> None:
+    """device tensor u16 (n, Y, X) -> n plane files, block by block through two pinned buffers: the download of
+    block k + 1 runs on a side stream while a writer thread puts block k on disk (utility.py:264, 355 write
+    file by file after the whole result is on the host)."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from . import _lib
+    paths = list(paths)
+    if planes.dim() != 3 or planes.shape[0] != len(paths) or planes.dtype != torch.uint16 or not planes.is_cuda:
+        raise ValueError("write_planes_from_device: planes must be a device uint16 tensor (n, Y, X), one path per plane")
+    planes = planes.contiguous()
+    n, y, x = planes.shape
+    blocks = _blocks(n, y, x, block_planes)
+    nb = max(b - a for a, b in blocks)
+    stage = [torch.empty((nb, y, x), dtype=torch.uint16, pin_memory=True) for _ in range(min(2, len(blocks)))]
+    side = torch.cuda.Stream(device=planes.device)
+    side.wait_stream(torch.cuda.current_stream(planes.device))      # the planes are final on the caller's stream
+    lib_threads = threads or IO_THREADS
+
+    def download(k):
+        a, b = blocks[k]
+        buf = stage[k % len(stage)]
+        with torch.cuda.stream(side):
+            buf[: b - a].copy_(planes[a:b], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return ev
+
+    def put(k, ev):
+        a, b = blocks[k]
+        ev.synchronize()
+        buf = stage[k % len(stage)]
+        _lib.check(_lib.load().iap_tiff_write_u16(_path_array(paths[a:b]), b - a, buf.data_ptr(), y, x, lib_threads),
+                   "iap_tiff_write_u16")
+
+    with ThreadPoolExecutor(1) as pool:
+        writing = [None] * len(stage)
+        ev = download(0)
+        for k in range(len(blocks)):
+            fut = pool.submit(put, k, ev)
+            writing[k % len(stage)] = fut
+            if k + 1 < len(blocks):
+                slot = (k + 1) % len(stage)
+                if writing[slot] is not None:
+                    writing[slot].result()          # that buffer's block is on disk
+                ev = download(k + 1)
+        for fut in writing:
+            if fut is not None:
+                fut.result()
 
 
 _TYPES = {1: ("B", 1), 2: ("c", 1), 3: ("H", 2), 4: ("I", 4), 5: ("II", 8), 16: ("Q", 8)}

@@ -107,6 +107,30 @@ def golden_morph():
     np.savez_compressed(os.path.join(HERE, "morph_scipy.npz"), labels=lab.astype(np.uint16), **out)
 
 
+def golden_tiff():
+    """Plane files as the reference writes them: tifffile.imwrite(path, plane.astype(np.uint16)) under the names of
+    utility.py:158-166 (chan_fNNNN_zNNNN.tif), :616-618 (mask_<chan>_fNNNN_zNNNN.tif) and :859-866
+    (mask_<label>_fNNNN.tif), plus a three-digit frame name (utility.py:587-588 reads either width).  Written by
+    tifffile 2021.7.2 -- the library the reference itself calls -- and read back in tests/test_tiffio_cpu.py by
+    iap_tiff_read_u16.  The expected arrays ride in tiff_planes.npz."""
+    import tifffile
+    d = os.path.join(HERE, "tiff")
+    os.makedirs(d, exist_ok=True)
+    rng = np.random.default_rng(7)
+    names = ["GFP_f0001_z0001.tif", "GFP_f0002_z0001.tif", "RFP_f0001_z0001.tif", "RFP_f0002_z0001.tif",
+             "BF_f001_z0001.tif", "mask_GFP_f0001_z0001.tif", "mask_wound_f0001.tif", "mask_wound_f0002.tif"]
+    planes = rng.integers(0, 65536, size=(len(names), 37, 53)).astype(np.float64)   # the reference holds floats here
+    planes[5:] = rng.integers(0, 4, size=(3, 37, 53))
+    for n, a in zip(names, planes):
+        tifffile.imwrite(os.path.join(d, n), a.astype(np.uint16))
+    # what the same library does with options the reference never passes (the batched reader must refuse these
+    # by name and the shim falls back to the generic reader): a compressed file and a float plane
+    tifffile.imwrite(os.path.join(d, "other_deflate.tif"), planes[0].astype(np.uint16), compression="zlib")
+    tifffile.imwrite(os.path.join(d, "other_float32.tif"), planes[0].astype(np.float32))
+    np.savez_compressed(os.path.join(HERE, "tiff_planes.npz"), names=np.array(names), planes=planes.astype(np.uint16),
+                        tifffile_version=np.array(tifffile.__version__))
+
+
 if __name__ == "__main__":
     golden_regionprops()
     golden_shift()
@@ -115,3 +139,4 @@ if __name__ == "__main__":
     print("golden fixtures written to", HERE)
     golden_edt()
     golden_morph()
+    golden_tiff()

@@ -203,3 +203,24 @@ def test_smo_bg_sub_with_sigma(dev, tmp_path):
         # the mask may differ on pixels whose SMO value lies within the fp32 band of the threshold; the median
         # of ~5 % of 32k pixels does not move with a handful of them on this input
         assert np.array_equal(got, eout)
+
+
+def test_staged_folder_io_round_trip(dev, tmp_path):
+    """tiffio.read_planes_to_device / write_planes_from_device: pinned staging blocks, several blocks per call,
+    a ragged last block (the shim's folder calls go through these)."""
+    import torch
+    rng = np.random.default_rng(31)
+    planes = rng.integers(0, 65536, size=(23, 45, 70), dtype=np.uint16)
+    paths = [str(tmp_path / ("GFP_f%04d_z0001.tif" % (i + 1))) for i in range(len(planes))]
+    tiffio.write_planes(paths, planes)
+    d = tiffio.read_planes_to_device(paths, dev, block_planes=5)
+    torch.cuda.synchronize()
+    assert d.dtype == torch.uint16 and d.is_cuda
+    assert np.array_equal(d.view(torch.int16).cpu().numpy().view(np.uint16), planes)
+    out = [str(tmp_path / ("out_f%04d_z0001.tif" % (i + 1))) for i in range(len(planes))]
+    tiffio.write_planes_from_device(out, d, block_planes=4)
+    assert np.array_equal(tiffio.read_planes(out), planes)
+    one = tiffio.read_planes_to_device(paths[:1], dev)           # a single block, a single plane
+    assert np.array_equal(one.view(torch.int16).cpu().numpy().view(np.uint16), planes[:1])
+    with pytest.raises(ValueError):
+        tiffio.read_planes_to_device([os.path.join(os.path.dirname(__file__), "golden", "tiff", "other_deflate.tif")], dev)

@@ -111,3 +111,50 @@ def test_shim_falls_back_for_other_sample_types(tmp_path):
         tiffio.imwrite(p, np.full((4, 6), i, np.uint8))
     got = pipeline._read_u16_planes(paths)
     assert got.dtype == np.uint16 and got.shape == (3, 4, 6) and [int(g[0, 0]) for g in got] == [0, 1, 2]
+
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_reads_files_written_by_tifffile():
+    """Fixtures written by tifffile.imwrite(plane.astype(uint16)) -- the very call of utility.py:166, 264, 355, 616 --
+    under the reference's file names (tests/golden/make_golden.py::golden_tiff, tifffile 2021.7.2)."""
+    d = np.load(os.path.join(GOLD, "tiff_planes.npz"))
+    names, planes = [str(n) for n in d["names"]], d["planes"]
+    paths = [os.path.join(GOLD, "tiff", n) for n in names]
+    assert tiffio.probe(paths[0]) == (37, 53, 16, 1, 1, 1)
+    assert np.array_equal(tiffio.read_planes(paths, threads=3), planes)          # iap_tiff_read_u16
+    for p, a in zip(paths, planes):                                              # and the pure-Python reader
+        assert np.array_equal(tiffio.imread(p), a)
+    # options the reference never passes: refused by name, so that the shim can fall back
+    for other in ("other_deflate.tif", "other_float32.tif"):
+        with pytest.raises(ValueError) as e:
+            tiffio.read_planes([os.path.join(GOLD, "tiff", other)], shape=(37, 53))
+        assert other in str(e.value)
+
+
+def test_shim_loaders_on_tifffile_fixtures(tmp_path):
+    """load_stack / load_mask of the shim on a folder of tifffile-written planes, three-digit frame numbers and
+    the reference-mask names without a z token included (utility.py:487-524, 558-595, 859-866)."""
+    import pickle
+    import shutil
+    from imageanalysis_pipeline_amd.pipeline import Utility
+    d = np.load(os.path.join(GOLD, "tiff_planes.npz"))
+    names, planes = [str(n) for n in d["names"]], d["planes"]
+    exp = tmp_path / "cond" / "s1_exp"
+    (exp / "Images").mkdir(parents=True)
+    (exp / "Masks_wound").mkdir()
+    for n in names:
+        sub = "Masks_wound" if n.startswith("mask_wound") else "Images"
+        shutil.copy(os.path.join(GOLD, "tiff", n), exp / sub / n)
+    prop = {"metadata": {"t": 2, "z": 1, "c": 2, "x": 53, "y": 37, "channel_list": ["GFP", "RFP"], "tag": "cond",
+                         "interval_sec": 60}, "img_preProcess": {}, "fct_inputs": {}, "masks_process": {}, "status": "active"}
+    with open(exp / "exp_properties.pickle", "wb") as fh:
+        pickle.dump(prop, fh)
+    st = Utility.load_stack(str(exp / "Images"))
+    assert st.shape == (2, 37, 53, 2)
+    assert np.array_equal(st[0, ..., 0], planes[0]) and np.array_equal(st[1, ..., 1], planes[3])
+    bf = Utility.load_stack(str(exp / "Images"), channel_list="BF", input_range=[0])     # BF_f001_z0001.tif
+    assert np.array_equal(bf, planes[4])
+    wound = Utility.load_mask(str(exp / "Masks_wound"), "wound", do_log=False)
+    assert np.array_equal(wound, planes[6:8])
