@@ -67,7 +67,8 @@ STAGE_OF_KERNEL = {
 }
 HARNESS_OF_STAGE = {"apply": lambda t, c, z, y, x: ["apply", t, c * z, y, x],
                     "bg": lambda t, c, z, y, x: ["bg", t * c * z, y, x],
-                    "measure": lambda t, c, z, y, x: ["measure", t, c, y, x]}
+                    "measure": lambda t, c, z, y, x: ["measure", t, c, y, x],
+                    "estimate": lambda t, c, z, y, x: ["estimate", t, y, x]}
 
 
 def spawn_ranks(n: int) -> int:

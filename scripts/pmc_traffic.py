@@ -27,13 +27,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HARNESS = os.path.join(ROOT, "scripts", "pmc_harness")
 
 
+_KERNEL = re.compile(r"iap::(\w+)|_ZN3iap\d+([A-Za-z0-9_]+?kernel)")
+
+
 def _per_kernel(path, counter):
     acc = collections.defaultdict(lambda: [0.0, 0])
     with open(path) as fh:
         for r in csv.DictReader(fh):
-            if r["Counter_Name"] != counter or "iap::" not in r["Kernel_Name"]:
+            m = _KERNEL.search(r["Kernel_Name"])      # demangled "iap::name<...>" or mangled "_ZN3iap<len>name..."
+            if r["Counter_Name"] != counter or not m:
                 continue
-            a = acc[re.search(r"iap::(\w+)", r["Kernel_Name"]).group(1)]
+            a = acc[m.group(1) or m.group(2)]
             a[0] += float(r["Counter_Value"]) * 1024.0
             a[1] += 1
     return acc
@@ -77,8 +81,12 @@ def measure(harness_args, timeout=120, keep=None):
         w, nw = write.get(k, [0.0, 0])
         fb = 2.0 * f / nf if nf else None
         wb = w / nw if nw else None
+        calls = 3.0       # the harness runs its stage once to warm up and IAP_HARNESS_REPS = 2 times more
         out[k] = {"hbm_bytes_per_launch": (fb or 0.0) + (wb or 0.0), "fetch_bytes_per_launch": fb,
                   "write_bytes_per_launch": wb, "launches_sampled": max(nf, nw),
+                  # kernels launched several times per call with unequal sizes (the estimate's: one small launch
+                  # for the reference, one per 64-frame group): the sum over a call is the meaningful figure
+                  "hbm_bytes_per_harness_call": (2.0 * f + w) / calls,
                   "config": "scripts/pmc_harness " + " ".join(str(a) for a in harness_args) + " (C-ABI of libiap_hip.so)",
                   "note": "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, rocprofv3 --pmc, one pass per counter"}
         if timing:
@@ -86,7 +94,7 @@ def measure(harness_args, timeout=120, keep=None):
     return out
 
 
-ALL = (["apply", 500, 4], ["bg", 2000], ["estimate", 128], ["measure", 500, 4], ["measure", 16, 1, 2048, 2048, "dense"])
+ALL = (["apply", 500, 4], ["bg", 2000], ["estimate", 128], ["measure", 500, 4], ["measure", 64, 1, 2048, 2048, "dense"])
 
 
 if __name__ == "__main__":
