@@ -25,6 +25,8 @@
 // truncate to u16.  An axis with an integer shift bypasses the filter: exact copies.
 #include <math.h>
 #include <stdlib.h>
+#include <algorithm>
+#include <atomic>
 #include "common.h"
 
 namespace iap {
@@ -60,11 +62,15 @@ __device__ __forceinline__ cf subi(cf c, cf d) {
 template <int SIGN> __device__ __forceinline__ cf add_si(cf c, cf d) { return SIGN < 0 ? subi(c, d) : addi(c, d); }
 template <int SIGN> __device__ __forceinline__ cf sub_si(cf c, cf d) { return SIGN < 0 ? addi(c, d) : subi(c, d); }
 
-// LDS index of sequence element i: an XOR swizzle of the low five bits, chosen per pass structure (8 points
-// per thread: radix-8 passes; 16 points: radix-16 passes) so that every pass is conflict-free in a 32-lane /
-// 64-bank model (a one-in-eight pad costs 1.75x-2x there; measured: -4 % on the column kernel)
+// LDS index of sequence element i.  8 points per thread (the row kernels): an XOR swizzle of the low five bits,
+// conflict-free for the radix-8 passes in a 32-lane / 64-bank model.  16 or 32 points per thread (the column
+// kernels): one pad element per 16, i + i / 16 -- every access of a pass is then one per-thread base plus a
+// compile-time offset (the DS instructions' immediate), where the swizzle cost three VALU instructions per
+// access, 40 % of all the column kernel issued; the padded passes stay conflict-free but for one lane pair.
 template <int E>
-__device__ __forceinline__ int padi(int i) { return E >= 16 ? (i ^ ((i >> 4) & 31)) : (i ^ ((i >> 3) & 31)); }
+__device__ __forceinline__ int padi(int i) { return E >= 16 ? (i + (i >> 4)) : (i ^ ((i >> 3) & 31)); }
+template <int E>
+constexpr int padk(int k) { return E >= 16 ? k + k / 16 : k; }   // padi(a + k) - padi(a) for 16 | k (and for k < 16 when 16 | a)
 
 template <int SIGN>
 __device__ __forceinline__ void dft2(cf* v) {
@@ -148,41 +154,83 @@ __device__ __forceinline__ void dftR(cf* v) {
   else dft2<SIGN>(v);
 }
 
+// Hand-over between the read half and the write half of a pass.  An FFT that one wave does on its own (N / E = 64)
+// needs no workgroup barrier: the LDS operations of a wave complete in order, the fence only pins the compiler.
+template <int NT>
+__device__ __forceinline__ void fft_sync() {
+#ifndef IAP_FFT_WG_BARRIER
+  if constexpr (NT == 64) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  } else
+#endif
+    __syncthreads();
+}
+
+// After a wave-private FFT, before other waves read its column: the workgroup barrier fft_sync left out.
+template <int NT>
+__device__ __forceinline__ void fft_publish() {
+#ifndef IAP_FFT_WG_BARRIER
+  if constexpr (NT == 64) __syncthreads();
+#endif
+}
+
 // One Stockham radix-R pass over an N-point sequence held in LDS (padded index), done by
-// N/E threads (E points each).  tw[k] = exp(-2 pi i k / N).  Ends with a barrier.
+// N/E threads (E points each).  tw[k] = exp(-2 pi i k / N).  Ends with a barrier (fft_sync).
 template <int N, int E, int R, int SIGN, int Ns>
 __device__ __forceinline__ void fft_pass(cf* s, int j, const cf* __restrict__ tw) {
   constexpr int NT = N / E;
   constexpr int NB = E / R;
   cf v[NB][R];
+  cf w1[NB];
+  // every read of the pass is issued before anything waits for one: left alone, the scheduler threads the reads
+  // one by one into the twiddle chain and each then costs a full LDS round trip
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int jj = j + b * NT;
+    if constexpr (E >= 16 && (N / R) % 16 == 0) {
+      const cf* sr = s + padi<E>(jj);
 #pragma unroll
-    for (int r = 0; r < R; ++r) v[b][r] = s[padi<E>(jj + r * (N / R))];
+      for (int r = 0; r < R; ++r) v[b][r] = sr[padk<E>(r * (N / R))];
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) v[b][r] = s[padi<E>(jj + r * (N / R))];
+    }
     if (Ns > 1) {
-      const int k = jj & (Ns - 1);
-      cf w1 = tw[k * (N / (Ns * R))];
-      if (SIGN > 0) w1.y = -w1.y;
+      static_assert((Ns - 1) * (N / (Ns * R)) < ((N / 2) < 256 ? (N / 2) : 256) || E == 8, "column passes stay inside the LDS twiddle table (FftGeom::TWL)");
+      w1[b] = tw[(jj & (Ns - 1)) * (N / (Ns * R))];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (Ns > 1) {
+      if (SIGN > 0) w1[b].y = -w1[b].y;
       // powers of w1 by a running product: two live twiddle registers instead of seven
-      cf w = w1;
+      cf w = w1[b];
 #pragma unroll
       for (int r = 1; r < R; ++r) {
         v[b][r] = cmul(v[b][r], w);
-        if (r + 1 < R) w = cmul(w, w1);
+        if (r + 1 < R) w = cmul(w, w1[b]);
       }
     }
     dftR<R, SIGN>(v[b]);
   }
-  __syncthreads();
+  fft_sync<NT>();
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int jj = j + b * NT;
     const int base = (jj / Ns) * (Ns * R) + (jj & (Ns - 1));
+    if constexpr (E >= 16 && (Ns % 16 == 0 || (Ns == 1 && R == 16))) {
+      cf* sw = s + padi<E>(base);          // Ns = 1: base = 16 jj, the r < 16 behind it share its pad
 #pragma unroll
-    for (int r = 0; r < R; ++r) s[padi<E>(base + r * Ns)] = v[b][r];
+      for (int r = 0; r < R; ++r) sw[Ns == 1 ? r : padk<E>(r * Ns)] = v[b][r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) s[padi<E>(base + r * Ns)] = v[b][r];
+    }
   }
-  __syncthreads();
+  fft_sync<NT>();
 }
 
 template <int N, int E, int SIGN, int Ns>
@@ -209,8 +257,14 @@ struct FftGeom {
   static constexpr int PADN = N + N / 8;                      // padded LDS points per FFT
   static constexpr int G = (256 / NT) > 1 ? (256 / NT) : 1;   // row FFTs per workgroup
   static constexpr int TC = (8192 / N) < 16 ? (8192 / N) : 16;  // columns per workgroup
-  static constexpr int CE = N >= 128 ? 16 : 8;                // points per thread in the column kernel
+#ifndef IAP_COL_E2048
+#define IAP_COL_E2048 16
+#endif
+  // points per thread in the column kernel; 32 at N = 2048 makes a column one wave's own (no barriers inside its FFT)
+  static constexpr int CE = N == 2048 ? IAP_COL_E2048 : (N >= 128 ? 16 : 8);
   static constexpr int CNT = N / CE;                          // threads per column FFT
+  static constexpr int CWPS = CE >= 32 ? 2 : 4;               // waves per SIMD the column kernels are compiled for (LDS allows no more)
+  static constexpr int TWL = (N / 2) < 256 ? (N / 2) : 256;   // twiddles the column passes index (k N / (Ns R) < N / R of the last pass)
   static constexpr int CS = PADN + 8;                         // LDS stride between columns: the column pairs a lane pair touches sit 16 bank pairs apart
 };
 
@@ -340,6 +394,11 @@ struct ColGeom {
   static_assert(TC % VW == 0 && CE % VW == 0 && (TC * N) % (NTH * VW) == 0, "whole chunks per thread");
   static_assert(TC % 2 == 0 && CE % 2 == 0, "column pairs for the float stores");
 };
+// the column kernels keep the twiddles their passes use in LDS: a pass then waits for an LDS read, not for L2
+template <int N>
+__device__ __forceinline__ void stage_twiddles(cf* tw_s, const cf* __restrict__ tw, int tid) {
+  for (int i = tid; i < FftGeom<N>::TWL; i += ColGeom<N>::NTH) tw_s[i] = tw[i];
+}
 template <int VW> struct HChunk;
 template <> struct HChunk<4> { typedef h8 T; };
 template <> struct HChunk<2> { typedef h4 T; };
@@ -353,7 +412,11 @@ __device__ __forceinline__ void load_half_tile(const h2* __restrict__ Ff, int Wp
 #pragma unroll
   for (int m = 0; m < Cg::NL; ++m) {
     const int idx = tid + m * Cg::NTH;
+#ifdef IAP_COL_X_NOLOADF
+    w[m] = *reinterpret_cast<const HC*>(Ff + (size_t)(idx % 64) * Cg::VW);
+#else
     w[m] = *reinterpret_cast<const HC*>(Ff + (size_t)(idx / Cg::CPR) * Wp + v0 + (idx % Cg::CPR) * Cg::VW);
+#endif
   }
 }
 template <int N>
@@ -382,6 +445,9 @@ __device__ __forceinline__ void store_float_tile(const cf* lds, cf* __restrict__
     const int idx = tid + m * Cg::NTH;
     const int pc = idx % HP, u = idx / HP;
     const cf a = lds[(2 * pc) * Cg::CS + padi<Cg::CE>(u)], b2 = lds[(2 * pc + 1) * Cg::CS + padi<Cg::CE>(u)];
+#ifdef IAP_COL_X_NOSTORE
+    if (a.x == 1.2345e-30f)
+#endif
     *reinterpret_cast<float4*>(Qf + (size_t)u * Wp + v0 + 2 * pc) = make_float4(a.x, a.y, b2.x, b2.y);
   }
 }
@@ -397,14 +463,16 @@ __device__ __forceinline__ cf xpower(cf g, cf f, float scale, int normalize) {
 }
 
 template <int N>
-__global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_ref_kernel(
+__global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, FftGeom<N>::CWPS) void cols_ref_kernel(
     const cf* __restrict__ F, long long F_stride, h2* __restrict__ G, long long G_stride, float* __restrict__ gscale,
     int gs_stride, int Wp, int nvalid, const cf* __restrict__ tw) {
   using Cg = ColGeom<N>;
   typedef typename HChunk<Cg::VW>::T HC;
   extern __shared__ cf lds_c[];
   __shared__ float wmax[16];
+  __shared__ cf tw_s[FftGeom<N>::TWL];
   const int tid = threadIdx.x;
+  stage_twiddles<N>(tw_s, tw, tid);
   const int c = tid / Cg::CNT, j = tid % Cg::CNT;
   const unsigned frame = blockIdx.y;
   const int tile = xcd_remap(blockIdx.x, gridDim.x), v0 = tile * Cg::TC;
@@ -427,7 +495,8 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_ref_k
     }
   }
   __syncthreads();
-  fft_lds<N, -1, Cg::CE>(lds_c + c * Cg::CS, j, tw);
+  fft_lds<N, -1, Cg::CE>(lds_c + c * Cg::CS, j, tw_s);
+  fft_publish<Cg::CNT>();
   // largest component of the tile -> power-of-two scale that brings it into [16384, 32768)
   cf v[Cg::NL][Cg::VW];
   float mx = 0.f;
@@ -469,35 +538,69 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_ref_k
   }
 }
 
+#ifdef IAP_COL_STAMPS
+// development aid: cycles per phase of the column kernel, summed over the first wave of every workgroup
+__device__ unsigned long long g_col_stamps[16];
+#define CS_INIT() long long cs_last = clock64(), cs_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define CS_STAMP(i) do { long long t_ = clock64(); cs_acc[i] += t_ - cs_last; cs_last = t_; } while (0)
+#define CS_FLUSH() do { if (tid == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&g_col_stamps[i_], (unsigned long long)cs_acc[i_]); atomicAdd(&g_col_stamps[15], 1ull); } } while (0)
+#else
+#define CS_INIT() do {} while (0)
+#define CS_STAMP(i) do {} while (0)
+#define CS_FLUSH() do {} while (0)
+#endif
 template <int N>
-__global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_xpower_kernel(
+__global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, FftGeom<N>::CWPS) void cols_xpower_kernel(
     const h2* __restrict__ F, long long F_stride, const h2* __restrict__ G, long long G_stride,
     const float* __restrict__ gscale, int gs_stride, cf* __restrict__ Q, long long Q_stride, int Wp, int nvalid,
-    const cf* __restrict__ tw, int normalize, float scale) {
+    const cf* __restrict__ tw, int normalize, float scale, int ntiles, int nitems) {
   using Cg = ColGeom<N>;
   typedef typename HChunk<Cg::VW>::T HC;
   extern __shared__ cf lds_c[];
-  const int tid = threadIdx.x;
-  const int c = tid / Cg::CNT, j = tid % Cg::CNT;
-  cf* s = lds_c + c * Cg::CS;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x), v0 = tile * Cg::TC;
-  const int f = blockIdx.y;
-  {
-    HC fa[Cg::NL];
-    load_half_tile<N>(F + (size_t)f * F_stride, Wp, v0, tid, fa);
+  const int tid0 = threadIdx.x;
+  __shared__ cf tw_s[FftGeom<N>::TWL];
+  stage_twiddles<N>(tw_s, tw, tid0);
+  // Persistent workgroups: item i = frame * ntiles + tile; a workgroup takes i = b, b + grid, ...  The workgroups of
+  // one XCD hold consecutive b, so at any moment an XCD works on neighbouring tiles of a frame and F's 128-byte lines
+  // are used up by one L2.  The next item's half tile and this item's chunks of the reference are requested before
+  // the forward FFT: the memory latency (most of a one-shot workgroup's life: of its 56 kcycles, 20 went to waiting
+  // for F and 10 for G) runs under the FFTs.
+  const int b = xcd_remap(blockIdx.x, gridDim.x);
+  CS_INIT();
+  HC fa[Cg::NL];
+  if (b < nitems) load_half_tile<N>(F + (size_t)(b / ntiles) * F_stride, Wp, (b % ntiles) * Cg::TC, tid0, fa);
+  for (int item = b; item < nitems; item += gridDim.x) {
+    const int f = item / ntiles, tile = item - f * ntiles, v0 = tile * Cg::TC;
+    // the thread index is made opaque per item: the LDS offsets of all passes depend on nothing else, and hoisted
+    // out of this loop they would fill the register file (spills wait on the same counter as the prefetch)
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int c = tid / Cg::CNT, j = tid % Cg::CNT;
+    cf* s = lds_c + c * Cg::CS;
+    CS_STAMP(0);
     stage_half_tile<N>(lds_c, v0, nvalid, tid, fa);
-  }
-  __syncthreads();
-  fft_lds<N, -1, Cg::CE>(s, j, tw);
-  {
-    // the reference's chunks: contiguous 16 bytes per lane, served by L2 / the Infinity Cache (every frame re-reads
-    // them); the registers of the FFT are free here, so all of the thread's values are requested at once
+    CS_STAMP(1);
+    __syncthreads();
+    CS_STAMP(2);
+    {
+      const int nx = item + gridDim.x;
+      if (nx < nitems) load_half_tile<N>(F + (size_t)(nx / ntiles) * F_stride, Wp, (nx % ntiles) * Cg::TC, tid, fa);
+    }
+    // the reference's chunks: contiguous 16 bytes per lane, served by L2 / the Infinity Cache (every frame re-reads them)
     const int gf = G_stride ? f : 0;
     const h2* Gt = G + (size_t)gf * G_stride + (size_t)v0 * N;
     const float sc = scale * gscale[(size_t)gf * gs_stride + tile];
     HC g[Cg::NL];
 #pragma unroll
+#ifdef IAP_COL_X_NOG
+    for (int m = 0; m < Cg::NL; ++m) g[m] = *reinterpret_cast<const HC*>(G + (size_t)(tid & 63) * Cg::VW);
+#else
     for (int m = 0; m < Cg::NL; ++m) g[m] = *reinterpret_cast<const HC*>(Gt + (size_t)(tid + m * Cg::NTH) * Cg::VW);
+#endif
+    fft_lds<N, -1, Cg::CE>(s, j, tw_s);
+    CS_STAMP(3);
+    fft_publish<Cg::CNT>();
+    CS_STAMP(4);
 #pragma unroll
     for (int m = 0; m < Cg::NL; ++m) {
       const int idx = tid + m * Cg::NTH;
@@ -510,14 +613,22 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 4) void cols_xpowe
         lds_c[at] = p;
       }
     }
+    CS_STAMP(5);
+    __syncthreads();
+    CS_STAMP(6);
+    fft_lds<N, +1, Cg::CE>(s, j, tw_s);
+    CS_STAMP(7);
+    fft_publish<Cg::CNT>();
+    CS_STAMP(8);
+    store_float_tile<N>(lds_c, Q + (size_t)f * Q_stride, Wp, v0, tid);
+    __syncthreads();   // the tile is free for the next item
+    CS_STAMP(9);
   }
-  __syncthreads();
-  fft_lds<N, +1, Cg::CE>(s, j, tw);
-  store_float_tile<N>(lds_c, Q + (size_t)f * Q_stride, Wp, v0, tid);
+  { const int tid = tid0; (void)tid; CS_FLUSH(); }
 }
 
 template <int N>
-__global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 2) void cols_fused_kernel(
+__global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, FftGeom<N>::CE >= 32 ? 1 : 2) void cols_fused_kernel(
     const h2* __restrict__ F, long long F_stride, const h2* __restrict__ Gref, long long G_stride,
     cf* __restrict__ Q, long long Q_stride, int Wp, int nvalid, const cf* __restrict__ tw, int normalize, float scale) {
   using Cg = ColGeom<N>;
@@ -528,6 +639,8 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 2) void cols_fused
   const unsigned frame = blockIdx.y;
   const int v0 = xcd_remap(blockIdx.x, gridDim.x) * Cg::TC;
   cf* const lds_g = lds_c + Cg::TC * Cg::CS;     // the reference's tile
+  __shared__ cf tw_s[FftGeom<N>::TWL];
+  stage_twiddles<N>(tw_s, tw, tid);
   {
     HC w[Cg::NL];
     load_half_tile<N>(F + (size_t)frame * F_stride, Wp, v0, tid, w);
@@ -536,8 +649,9 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 2) void cols_fused
     stage_half_tile<N>(lds_g, v0, nvalid, tid, w);
   }
   __syncthreads();
-  fft_lds<N, -1, Cg::CE>(lds_c + c * Cg::CS, j, tw);
-  fft_lds<N, -1, Cg::CE>(lds_g + c * Cg::CS, j, tw);
+  fft_lds<N, -1, Cg::CE>(lds_c + c * Cg::CS, j, tw_s);
+  fft_lds<N, -1, Cg::CE>(lds_g + c * Cg::CS, j, tw_s);
+  fft_publish<Cg::CNT>();
 #pragma unroll
   for (int m = 0; m < Cg::NL; ++m) {
     const int idx = tid + m * Cg::NTH;
@@ -551,7 +665,8 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 2) void cols_fused
     }
   }
   __syncthreads();
-  fft_lds<N, +1, Cg::CE>(lds_c + c * Cg::CS, j, tw);
+  fft_lds<N, +1, Cg::CE>(lds_c + c * Cg::CS, j, tw_s);
+  fft_publish<Cg::CNT>();
   store_float_tile<N>(lds_c, Q + (size_t)frame * Q_stride, Wp, v0, tid);
 }
 
@@ -1629,6 +1744,19 @@ static int launch_cols_ref(const RegPlan& p, const cf* F, long long F_stride, h2
 }
 
 // n moving frames (half row spectra F) against G (one for all: G_stride 0, or one per frame) -> Q (float)
+// workgroups of a column kernel that are resident at once on this device (0 on error)
+template <typename K>
+static int cols_resident(K kernel, int threads, size_t lds) {
+  static std::atomic<int> known[64];          // per kernel instantiation and device; the queries are slow
+  int per_cu = 0, dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (dev >= 0 && dev < 64 && known[dev].load() > 0) return known[dev].load();
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess) return 0;
+  if (dev >= 0 && dev < 64) known[dev].store(per_cu * cus);
+  return per_cu * cus;
+}
+
 static int launch_cols_xpower(const RegPlan& p, const h2* F, const h2* G, long long G_stride, const float* gscale,
                               cf* Q, int n, const cf* tw_y, int normalize, hipStream_t st) {
   // F holds F_true * 0.5 / Px (fs16), G holds G_true / gscale: P = G conj(F) / (Py Px) needs 2 Px / (Py Px)
@@ -1638,9 +1766,13 @@ static int launch_cols_xpower(const RegPlan& p, const h2* F, const h2* G, long l
     size_t lds = (size_t)Gm::TC * Gm::CS * sizeof(cf);
     IAP_HIP(allow_lds(cols_xpower_kernel<N>, lds));
     ProfScope ps_(K_COLS, st);
-    hipLaunchKernelGGL(cols_xpower_kernel<N>, dim3(valid_tiles(p), n), dim3(Gm::TC * Gm::CNT), lds, st, F,
-                       spec16_stride(p), G, G_stride, gscale, p.col_blocks, Q, spec32_stride(p), p.Wp, p.Px / 2 + 1,
-                       tw_y, normalize, scale);
+    const long long items = (long long)valid_tiles(p) * n;
+    if (items > 0x7fffffffLL) return IAP_E_UNSUPPORTED;
+    const int resident = cols_resident(cols_xpower_kernel<N>, Gm::TC * Gm::CNT, lds);
+    if (resident < 1) return (int)hipErrorUnknown;
+    hipLaunchKernelGGL(cols_xpower_kernel<N>, dim3((unsigned)std::min<long long>(items, resident)), dim3(Gm::TC * Gm::CNT),
+                       lds, st, F, spec16_stride(p), G, G_stride, gscale, p.col_blocks, Q, spec32_stride(p), p.Wp,
+                       p.Px / 2 + 1, tw_y, normalize, scale, valid_tiles(p), (int)items);
   });
   IAP_LAUNCH_CHECK();
   return IAP_OK;
@@ -1803,6 +1935,14 @@ static int launch_apply(const uint16_t* in, uint16_t* out, long long n_frames, l
 }  // namespace iap
 
 using namespace iap;
+
+#ifdef IAP_COL_STAMPS
+extern "C" void iap_debug_col_stamps(unsigned long long* host16) {
+  (void)hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_col_stamps), 16 * sizeof(unsigned long long));
+  unsigned long long z[16] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_col_stamps), z, sizeof(z));
+}
+#endif
 
 extern "C" int iap_mip_u16(const uint16_t* in, int64_t in_stride, uint16_t* out, int64_t n, int Z, int Y, int X,
                            void* stream) {

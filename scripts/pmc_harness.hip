@@ -7,6 +7,7 @@
 //   pmc_harness measure  <frames> <C> [Y X] [dense]   iap_measure_labels_u16; 300 discs per frame, or the 5041-label grid
 // Prints the mean wall time per call (HIP events) so a run without the profiler doubles as a micro-benchmark.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -118,6 +119,11 @@ int main(int argc, char** argv) {
       h[2 * i] = dy; h[2 * i + 1] = dx;
     }
     h[0] = h[1] = 0.0;
+    if (const char* m = getenv("IAP_HARNESS_SHIFT"))   // experiments: "y", "x" or "yx" makes those axes' shifts whole numbers
+      for (long long i = 0; i < n; ++i) {
+        if (strchr(m, 'y')) h[2 * i] = floor(h[2 * i]);
+        if (strchr(m, 'x')) h[2 * i + 1] = floor(h[2 * i + 1]);
+      }
     CK(hipMemcpy(sh, h.data(), (size_t)n * 16, hipMemcpyHostToDevice));
     IAP(iap_apply_shift_u16(in, out, n, C, Y, X, sh, nullptr));
     CK(hipEventRecord(e0));
@@ -162,6 +168,14 @@ int main(int argc, char** argv) {
   }
   CK(hipEventSynchronize(e1));
   CK(hipEventElapsedTime(&ms, e0, e1));
+  // development builds of the library (-DIAP_COL_STAMPS) export per-phase cycle sums of the column kernel
+  if (void* fn = dlsym(RTLD_DEFAULT, "iap_debug_col_stamps")) {
+    unsigned long long st[16];
+    ((void (*)(unsigned long long*))fn)(st);
+    fprintf(stderr, "col stamps (cycles per workgroup, %llu workgroups):", st[15]);
+    for (int i = 0; i < 10; ++i) fprintf(stderr, " %.0f", st[15] ? (double)st[i] / (double)st[15] : 0.0);
+    fprintf(stderr, "\n");
+  }
   printf("{\"stage\": \"%s\", \"n\": %lld, \"C\": %d, \"Y\": %d, \"X\": %d, \"dense\": %d, \"ms_per_call\": %.4f, \"reps\": %d}\n",
          stage, n, C, Y, X, dense, ms / reps, reps);
   return 0;

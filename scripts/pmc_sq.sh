@@ -10,8 +10,9 @@ import csv,sys,glob,collections,re
 acc=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob(sys.argv[1]+'/**/*counter_collection.csv',recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'iap::' not in r['Kernel_Name']: continue
-        k=re.search(r'iap::(\w+)',r['Kernel_Name']).group(1)
+        m=re.search(r'iap(?:::|[0-9]+)([A-Za-z_][A-Za-z_0-9]*?kernel)',r['Kernel_Name'])
+        if not m: continue
+        k=m.group(1)
         acc[k][r['Counter_Name']]+=float(r['Counter_Value']); cnt[k][r['Counter_Name']]+=1
         acc[k]['_dur_'+r['Counter_Name']]+=float(r['End_Timestamp'])-float(r['Start_Timestamp'])
 for k in acc:
