@@ -1462,9 +1462,14 @@ __global__ __launch_bounds__(256, AM_MIN_WAVES) void apply_shift_kernel(const ui
       } else {
         spline_run2<AM_G>(smp, rest, ax.w, res);
       }
-      v2f* d = colp + (AM_G * m) * AM_CP + jbase + r;
+      // colp row p holds the NEIGHBOURING columns (2p, 2p+1): the y pass then ends in one 4-byte store per lane and
+      // row.  Run m's eight outputs are the pairs 4m .. 4m+3, run m+4's the pairs 16 + 4m ..
+      v2f* d = colp + (AM_G / 2 * m) * AM_CP + jbase + r;
 #pragma unroll
-      for (int k = 0; k < AM_G; ++k) d[k * AM_CP] = res[k];
+      for (int q = 0; q < AM_G / 2; ++q) {
+        d[q * AM_CP] = (v2f){res[2 * q].x, res[2 * q + 1].x};
+        d[(AP_TX / 4 + q) * AM_CP] = (v2f){res[2 * q].y, res[2 * q + 1].y};
+      }
     }
   };
 
@@ -1523,18 +1528,20 @@ __global__ __launch_bounds__(256, AM_MIN_WAVES) void apply_shift_kernel(const ui
       } else {
         spline_run2<AM_G>(smp, rest, ay.w, res);
       }
-      const int xa = ox + pr, xb = xa + 32;
+      const int xa = ox + 2 * pr, xb = xa + 1;
+      const bool pair_store = (X & 1) == 0 && (reinterpret_cast<size_t>(out) & 3) == 0;   // both pixels of a lane in one aligned dword
       const bool interior = ox >= ax.lo && ox + AP_TX - 1 <= ax.hi && oy >= ay.lo && oy + AM_TY - 1 <= ay.hi &&
-                            ox + AP_TX <= X && oy + AM_TY <= Y;
+                            ox + AP_TX <= X && oy + AM_TY <= Y && pair_store;
       if (interior) {   // uniform: every output has its source inside the image and lies inside the plane
-        uint16_t* o0 = po + (size_t)(oy + y0) * X + xa;
+        unsigned* o0 = reinterpret_cast<unsigned*>(po + (size_t)(oy + y0) * X + xa);
 #pragma unroll
         for (int k = 0; k < AM_G; ++k) {   // clamp, then truncation toward zero; written once, not re-read here
 #ifdef AP_X_NOSTORE
           if (res[k].x != 1.2345e-30f) continue;
 #endif
-          __builtin_nontemporal_store((uint16_t)(unsigned)__builtin_amdgcn_fmed3f(res[k].x, 0.f, 65535.f), o0 + (size_t)k * X);
-          __builtin_nontemporal_store((uint16_t)(unsigned)__builtin_amdgcn_fmed3f(res[k].y, 0.f, 65535.f), o0 + (size_t)k * X + 32);
+          const unsigned a = (unsigned)__builtin_amdgcn_fmed3f(res[k].x, 0.f, 65535.f);
+          const unsigned b = (unsigned)__builtin_amdgcn_fmed3f(res[k].y, 0.f, 65535.f);
+          __builtin_nontemporal_store(a | (b << 16), o0 + (size_t)k * (X >> 1));
         }
       } else {
         const bool ain = xa >= ax.lo && xa <= ax.hi, bin = xb >= ax.lo && xb <= ax.hi;
@@ -1545,8 +1552,12 @@ __global__ __launch_bounds__(256, AM_MIN_WAVES) void apply_shift_kernel(const ui
           if (yy < Y) {
             const float va = ain && yin ? fminf(fmaxf(res[k].x, 0.f), 65535.f) : 0.f;
             const float vb = bin && yin ? fminf(fmaxf(res[k].y, 0.f), 65535.f) : 0.f;
-            if (xa < X) __builtin_nontemporal_store((uint16_t)(unsigned)va, po + (size_t)yy * X + xa);
-            if (xb < X) __builtin_nontemporal_store((uint16_t)(unsigned)vb, po + (size_t)yy * X + xb);
+            if (pair_store) {
+              if (xa < X) __builtin_nontemporal_store((unsigned)va | ((unsigned)vb << 16), reinterpret_cast<unsigned*>(po + (size_t)yy * X + xa));
+            } else {
+              if (xa < X) __builtin_nontemporal_store((uint16_t)(unsigned)va, po + (size_t)yy * X + xa);
+              if (xb < X) __builtin_nontemporal_store((uint16_t)(unsigned)vb, po + (size_t)yy * X + xb);
+            }
           }
         }
       }

@@ -96,17 +96,18 @@ def measure_labels(img: torch.Tensor, labels: torch.Tensor, n_labels: int | None
     """regionprops-style tables per frame with the reference's label selection: the labels
     present in the frame minus the smallest one (analysis.py:80 ``np.unique(mask)[1:]``).
 
-    Returns a list (one dict per frame) of numpy arrays: ids, area, mean (n,C), centroid
-    (n,ndim) and centroid_rne (n,ndim) with axis order (z,) y, x."""
+    Returns a list (one dict per frame) of numpy arrays: ids, area, sum (n,C; exact int64 intensity sums),
+    mean (n,C), centroid (n,ndim) and centroid_rne (n,ndim) with axis order (z,) y, x."""
     acc = measure_accumulate(img, labels, n_labels)
     area, mean, cen, cen_r = (a.cpu().numpy() for a in measure_finalize(acc))
+    sums = acc[:, :, 4:].cpu().numpy()
     z = img.shape[2]
     out = []
     for f in range(img.shape[0]):
         present = np.nonzero(area[f])[0]
         ids = present[1:]
         sl = slice(0, 3) if z > 1 else slice(1, 3)
-        out.append({"ids": ids.astype(np.int64), "area": area[f, ids], "mean": mean[f, ids],
+        out.append({"ids": ids.astype(np.int64), "area": area[f, ids], "sum": sums[f, ids], "mean": mean[f, ids],
                     "centroid": cen[f, ids][:, sl], "centroid_rne": cen_r[f, ids][:, sl]})
     return out
 

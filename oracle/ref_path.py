@@ -450,12 +450,14 @@ def chan_shift_stack(stack: np.ndarray, reg_channel: int = 0, upsample: bool = T
 
 def measure_labels_literal(img: np.ndarray, labels: np.ndarray):
     """The reference's own loop.  img: (C, [Z,] Y, X) u16; labels: ([Z,] Y, X).
-    Returns dict with ids, area, mean (n, C) f64, centroid_rne (n, ndim) int,
-    centroid (n, ndim) f64 -- axis order (z,) y, x."""
+    Returns dict with ids, area, sum (n, C) int64, mean (n, C) f64, centroid_rne (n, ndim) int,
+    centroid (n, ndim) f64 -- axis order (z,) y, x.  (The reference tabulates the mean; the sum is the
+    north-star's extra column, the exact integer the mean is the quotient of.)"""
     ids = list(np.unique(labels))[1:]            # analysis.py:80 drops the smallest value
     c = img.shape[0]
     nd = labels.ndim
     mean = np.zeros((len(ids), c), dtype=np.float64)
+    tot = np.zeros((len(ids), c), dtype=np.int64)
     cen = np.zeros((len(ids), nd), dtype=np.float64)
     cen_r = np.zeros((len(ids), nd), dtype=np.int64)
     area = np.zeros(len(ids), dtype=np.int64)
@@ -463,13 +465,14 @@ def measure_labels_literal(img: np.ndarray, labels: np.ndarray):
         sel = labels == obj
         for ch in range(c):
             mean[i, ch] = np.nanmean(a=img[ch], where=sel)      # analysis.py:98
+            tot[i, ch] = int(np.asarray(img[ch])[sel].astype(np.int64).sum())
         coords = np.where(sel)                                    # analysis.py:164/169
         area[i] = coords[0].size
         for d in range(nd):
             m = np.nanmean(coords[d])
             cen[i, d] = m
             cen_r[i, d] = round(m)                                # round-half-even on np.float64
-    return {"ids": np.asarray(ids, dtype=np.int64), "area": area, "mean": mean,
+    return {"ids": np.asarray(ids, dtype=np.int64), "area": area, "sum": tot, "mean": mean,
             "centroid": cen, "centroid_rne": cen_r}
 
 
@@ -484,16 +487,18 @@ def measure_labels(img: np.ndarray, labels: np.ndarray):
     c = img.shape[0]
     nd = labels.ndim
     mean = np.zeros((len(ids), c), dtype=np.float64)
+    tot = np.zeros((len(ids), c), dtype=np.int64)
     for ch in range(c):
         s = np.bincount(lab, weights=np.asarray(img[ch]).astype(np.float64).ravel(), minlength=nb)
         mean[:, ch] = s[ids] / cnt[ids].astype(np.float64)
+        tot[:, ch] = s[ids].astype(np.int64)                      # exact: the sums stay below 2**53
     grids = np.indices(labels.shape)
     cen = np.zeros((len(ids), nd), dtype=np.float64)
     for d in range(nd):
         s = np.bincount(lab, weights=grids[d].astype(np.float64).ravel(), minlength=nb)
         cen[:, d] = s[ids] / cnt[ids].astype(np.float64)
     cen_r = np.rint(cen).astype(np.int64)                         # rint == round-half-even
-    return {"ids": ids.astype(np.int64), "area": cnt[ids].astype(np.int64), "mean": mean,
+    return {"ids": ids.astype(np.int64), "area": cnt[ids].astype(np.int64), "sum": tot, "mean": mean,
             "centroid": cen, "centroid_rne": cen_r}
 
 

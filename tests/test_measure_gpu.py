@@ -22,6 +22,7 @@ def _check(img, lab, dev, n_labels=None):
         g = got[f]
         assert np.array_equal(g["ids"], exp["ids"])
         assert np.array_equal(g["area"], exp["area"])
+        assert g["sum"].dtype == np.int64 and np.array_equal(g["sum"], exp["sum"]), "per-label intensity sums"
         assert np.array_equal(g["mean"].view(np.uint64), exp["mean"].view(np.uint64)), "mean not bit-exact"
         assert np.array_equal(g["centroid"].view(np.uint64), exp["centroid"].view(np.uint64))
         assert np.array_equal(g["centroid_rne"], exp["centroid_rne"])
@@ -47,6 +48,7 @@ def test_literal_loop_agrees(dev):
     assert np.array_equal(got["mean"].view(np.uint64), exp["mean"].view(np.uint64))
     assert np.array_equal(got["centroid_rne"], exp["centroid_rne"])
     assert np.array_equal(got["area"], exp["area"])
+    assert np.array_equal(got["sum"], exp["sum"])
 
 
 def test_volumetric_labels(dev):

@@ -14,6 +14,7 @@ def test_known_answer():
     r = O.measure_labels(img, lab)
     assert list(r["ids"]) == [2, 5]
     assert list(r["area"]) == [4, 6]
+    assert r["sum"].tolist() == [[140], [1140]]
     assert r["mean"][0, 0] == (0 + 10 + 60 + 70) / 4
     assert r["mean"][1, 0] == sum(10 * v for v in (15, 16, 17, 21, 22, 23)) / 6
     assert r["centroid"].tolist() == [[0.5, 0.5], [2.5, 4.0]]
