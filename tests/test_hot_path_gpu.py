@@ -1,0 +1,143 @@
+"""``ops.hot_path`` -- the one call `bench.py` times and `distributed.process_plate` makes per FOV
+(core.py:99-112 + 328-330: smo_bg_sub -> im_reg -> per-label tables) -- against the staged calls it replaces,
+against the oracle, in its time-block form, and on the edge cases the stages meet in practice (a single frame,
+a blank frame in the middle of a stack, frames without labels).  Bars: DESIGN.md section 2.
+"""
+import numpy as np
+import pytest
+import torch
+
+from imageanalysis_pipeline_amd import ops, synth
+from oracle import ref_path as O
+
+pytestmark = pytest.mark.gpu
+
+THR = 0.0455
+
+
+def _labels(t, z, y, x, n, seed=0):
+    lab2 = synth.make_labels(y, x, n, seed=seed)
+    return np.broadcast_to(lab2[None, None], (t, z, y, x)).copy()
+
+
+def _tables_np(tables):
+    return [a.cpu().numpy() for a in tables]
+
+
+@pytest.mark.parametrize("reg_ref", ["first", "mean", "previous"])
+def test_hot_path_equals_staged_calls_and_oracle(dev, reg_ref):
+    """integer drift: one call == bg_smo -> im_reg -> measure bit for bit == the oracle's run_path"""
+    t, c, y, x = 5, 2, 128, 192
+    st, _ = synth.make_stack(t, c, 1, y, x, n_cells=12, integer_drift=True, seed=4)
+    lab = _labels(t, 1, y, x, 9)
+    d, dl = ops.to_device_u16(st, dev), ops.to_device_u16(lab, dev)
+    tables, shifts, levels = ops.hot_path(d, dl, THR, reg_channel=0, reg_ref=reg_ref, upsample=False, batch=2)
+    area, mean, cen, cen_r = _tables_np(tables)
+    # staged
+    bg, med2, _ = ops.bg_smo(d, THR)
+    reg, sh2 = ops.im_reg(bg, 0, reg_ref, upsample=False, batch=2)
+    acc = ops.measure_accumulate(reg, dl)
+    a2, m2, c2, r2 = _tables_np(ops.measure_finalize(acc))
+    assert torch.equal(levels, med2.view(-1))
+    assert torch.equal(shifts, sh2)
+    assert np.array_equal(area, a2) and np.array_equal(mean.view(np.uint64), m2.view(np.uint64))
+    assert np.array_equal(cen.view(np.uint64), c2.view(np.uint64)) and np.array_equal(cen_r, r2)
+    # oracle
+    _, es, et = O.run_path_opts(st, lab, THR, reg_ref, upsample=False)
+    assert np.array_equal(shifts.cpu().numpy(), es)
+    for f in range(t):
+        ids = et[f]["ids"]
+        assert np.array_equal(np.nonzero(area[f])[0][1:], ids)
+        assert np.array_equal(area[f, ids], et[f]["area"])
+        assert np.array_equal(mean[f, ids].view(np.uint64), et[f]["mean"].view(np.uint64))
+        assert np.array_equal(cen_r[f, ids][:, 1:], et[f]["centroid_rne"])
+
+
+@pytest.mark.parametrize("reg_ref", ["first", "mean"])
+@pytest.mark.parametrize("z", [1, 3])
+def test_time_blocks_equal_whole_stack(dev, reg_ref, z):
+    """the block-wise form (C3: the registered copy does not fit beside the stack) gives the whole-stack call's
+    shifts, levels and tables bit for bit, sub-pixel drift included; blocks that do not divide T"""
+    t, c, y, x = 7, 2, 96, 160
+    st, _ = synth.make_stack(t, c, z, y, x, n_cells=10, integer_drift=False, seed=8)
+    lab = _labels(t, z, y, x, 7, seed=2)
+    d, dl = ops.to_device_u16(st, dev), ops.to_device_u16(lab, dev)
+    whole = ops.hot_path(d, dl, THR, reg_ref=reg_ref)
+    for tb in (1, 3, 7, 50):
+        blk = ops.hot_path(d, dl, THR, reg_ref=reg_ref, tblock=tb)
+        assert torch.equal(blk[1], whole[1]), f"shifts, tblock={tb}"
+        assert torch.equal(blk[2], whole[2])
+        for a, b in zip(blk[0], whole[0]):
+            assert torch.equal(a, b), f"tables, tblock={tb}"
+
+
+def test_time_blocks_refuse_previous(dev):
+    st, _ = synth.make_stack(3, 1, 1, 64, 64, n_cells=3, integer_drift=True, seed=1)
+    lab = _labels(3, 1, 64, 64, 2)
+    with pytest.raises(ValueError, match="previous"):
+        ops.hot_path(ops.to_device_u16(st, dev), ops.to_device_u16(lab, dev), THR, reg_ref="previous", tblock=2)
+
+
+@pytest.mark.parametrize("reg_ref", ["first", "mean", "previous"])
+def test_single_frame_stack(dev, reg_ref):
+    """T = 1: the frame is its own reference in every mode -> shift 0, the stack comes back background-subtracted"""
+    st, _ = synth.make_stack(1, 2, 1, 128, 128, n_cells=6, integer_drift=True, seed=3)
+    lab = _labels(1, 1, 128, 128, 4)
+    d = ops.to_device_u16(st, dev)
+    out = torch.empty_like(d)
+    tables, shifts, levels = ops.hot_path(d, ops.to_device_u16(lab, dev), THR, reg_ref=reg_ref, out=out)
+    eo, es, et = O.run_path(st, lab, THR, reg_ref)
+    assert np.array_equal(es, [[0.0, 0.0]])
+    area, mean = tables[0].cpu().numpy(), tables[1].cpu().numpy()
+    ids = et[0]["ids"]
+    assert np.array_equal(area[0, ids], et[0]["area"])
+    if reg_ref == "mean":
+        # the mean of one frame is that frame, but it takes the reference's way through the kernels (f32 sums, its own
+        # half-pair scale): the refined shift is zero to 1e-4 px, not to the bit, and the warp is then the fractional one
+        sh = shifts.cpu().numpy()
+        assert np.abs(sh).max() < 1e-3
+        got = ops.to_numpy_u16(out)
+        for ch in range(2):   # the oracle's warp at the shift the GPU found (a source coordinate 4e-5 px outside
+            # the plane is outside: the border column is cval = 0, as scipy.ndimage.shift has it)
+            exp = O.apply_shift(O.bg_smo(st[0, ch, 0], THR)[0], sh[0, 0], sh[0, 1])
+            assert np.abs(got[0, ch, 0].astype(np.int64) - exp.astype(np.int64)).max() <= 1
+        return
+    assert shifts.cpu().numpy().tolist() == [[0.0, 0.0]]
+    assert np.array_equal(ops.to_numpy_u16(out), eo)
+    assert np.array_equal(mean[0, ids].view(np.uint64), et[0]["mean"].view(np.uint64))
+
+
+@pytest.mark.parametrize("reg_ref", ["first", "mean"])
+def test_blank_frame_in_the_stack(dev, reg_ref):
+    """an all-zero frame (a dropped acquisition): its cross-power is zero everywhere; no NaN, and the shift the
+    oracle gives for it (the arg-max of a zero surface: 0, 0)"""
+    t, y, x = 4, 128, 128
+    st, _ = synth.make_stack(t, 1, 1, y, x, n_cells=8, integer_drift=True, seed=6)
+    st[2] = 0
+    lab = _labels(t, 1, y, x, 5)
+    d = ops.to_device_u16(st, dev)
+    out = torch.empty_like(d)
+    tables, shifts, _ = ops.hot_path(d, ops.to_device_u16(lab, dev), THR, reg_ref=reg_ref, upsample=False, out=out)
+    sh = shifts.cpu().numpy()
+    assert np.isfinite(sh).all()
+    eo, es, _ = O.run_path_opts(st, lab, THR, reg_ref, upsample=False)
+    assert np.array_equal(sh, es)
+    assert np.array_equal(ops.to_numpy_u16(out), eo)
+    assert not ops.to_numpy_u16(out)[2].any()
+    assert np.isfinite(tables[1].cpu().numpy()).all()
+
+
+def test_frames_without_labels(dev):
+    """label planes that are all background in some frames (and in all of them): empty tables, area[0] = Y*X"""
+    t, y, x = 3, 64, 96
+    st, _ = synth.make_stack(t, 2, 1, y, x, n_cells=4, integer_drift=True, seed=9)
+    lab = _labels(t, 1, y, x, 3)
+    lab[1] = 0
+    d = ops.to_device_u16(st, dev)
+    (area, mean, _, _), _, _ = ops.hot_path(d, ops.to_device_u16(lab, dev), THR, reg_ref="first", upsample=False)
+    area = area.cpu().numpy()
+    assert area[1, 0] == y * x and not area[1, 1:].any()
+    assert not mean.cpu().numpy()[1].any()
+    lab[:] = 0
+    (area, _, _, _), _, _ = ops.hot_path(d, ops.to_device_u16(lab, dev), THR, reg_ref="first", upsample=False)
+    assert area.shape == (t, 1) and (area.cpu().numpy() == y * x).all()
