@@ -35,6 +35,7 @@ SIGNATURES = {
     "iap_im_reg_u16": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "iap_im_reg_sub_u16": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "iap_measure_labels_u16": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "iap_measure_labels_max_u16": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "iap_measure_finalize": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "iap_max_u16": (_i32, [_vp, _i64, _vp, _vp]),
     "iap_edt_ws_bytes": (_sz, [_i64, _i32, _i32]),

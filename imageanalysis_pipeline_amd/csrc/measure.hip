@@ -33,6 +33,7 @@ struct MeasTable {
   unsigned sx[MEAS_HASH];
   unsigned si[NC][MEAS_HASH];
   unsigned bg;
+  unsigned mx;   // largest label the workgroup saw (only kept when the caller asks for the frame maxima)
 };
 
 template <int NC, bool COORDS>
@@ -79,7 +80,7 @@ __device__ __forceinline__ void meas_flush_run(MeasTable<NC>& tb, unsigned lab, 
 template <int NC, bool COORDS, int VEC>
 __global__ __launch_bounds__(MEAS_THREADS) void measure_kernel(
     const uint16_t* __restrict__ img, const uint16_t* __restrict__ labels, unsigned zyx, int C, int c0,
-    int Y, int X, int L, unsigned long long* __restrict__ acc) {
+    int Y, int X, int L, unsigned long long* __restrict__ acc, unsigned* __restrict__ frame_max) {
   __shared__ MeasTable<NC> tb;
   const int tid = threadIdx.x;
   const unsigned t = blockIdx.y;
@@ -93,7 +94,10 @@ __global__ __launch_bounds__(MEAS_THREADS) void measure_kernel(
 #pragma unroll
     for (int c = 0; c < NC; ++c) tb.si[c][s] = 0;
   }
-  if (tid == 0) tb.bg = 0;
+  if (tid == 0) {
+    tb.bg = 0;
+    tb.mx = 0;
+  }
   __syncthreads();
 
   const uint16_t* lab_f = labels + (size_t)t * zyx;
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(MEAS_THREADS) void measure_kernel(
   const unsigned chunk = MEAS_THREADS * MEAS_ITERS * VEC;
   const unsigned chunk0 = blockIdx.x * chunk;
   const unsigned yx = (unsigned)Y * (unsigned)X;
-  unsigned bg = 0;
+  unsigned bg = 0, mx = 0;
 
 #pragma unroll 2
   for (int it = 0; it < MEAS_ITERS; ++it) {
@@ -123,6 +127,10 @@ __global__ __launch_bounds__(MEAS_THREADS) void measure_kernel(
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) lv[i] = l8.v[i];
+      if (frame_max) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mx = max(mx, (unsigned)lv[i]);
+      }
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         u16x8 i8 = load8_nt(img_f + (size_t)c * zyx + p);   // image planes stream through once
@@ -131,6 +139,7 @@ __global__ __launch_bounds__(MEAS_THREADS) void measure_kernel(
       }
     } else {
       lv[0] = lab_f[p];
+      if (frame_max) mx = max(mx, (unsigned)lv[0]);
 #pragma unroll
       for (int c = 0; c < NC; ++c) iv[c][0] = img_f[(size_t)c * zyx + p];
     }
@@ -175,7 +184,13 @@ __global__ __launch_bounds__(MEAS_THREADS) void measure_kernel(
     for (int o = 32; o > 0; o >>= 1) bg += __shfl_down(bg, o, 64);
     if ((tid & 63) == 0 && bg) atomicAdd(&tb.bg, bg);
   }
+  if (frame_max) {   // uniform
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_down(mx, o, 64));
+    if ((tid & 63) == 0 && mx) atomicMax(&tb.mx, mx);
+  }
   __syncthreads();
+  if (frame_max && tid == 0 && tb.mx) atomicMax(frame_max + t, tb.mx);
   for (int s = tid; s < MEAS_HASH; s += MEAS_THREADS) {
     unsigned lab = tb.key[s];
     if (lab) {
@@ -229,19 +244,19 @@ __global__ __launch_bounds__(256) void max_u16_kernel(const uint16_t* __restrict
 
 template <int NC, bool COORDS>
 static int launch_measure(const uint16_t* img, const uint16_t* labels, int64_t T, int C, int c0, int Z,
-                          int Y, int X, int L, uint64_t* acc, hipStream_t st) {
+                          int Y, int X, int L, uint64_t* acc, unsigned* frame_max, hipStream_t st) {
   unsigned zyx = (unsigned)((int64_t)Z * Y * X);
   auto* a = reinterpret_cast<unsigned long long*>(acc);
   if (zyx % 8 == 0) {
     unsigned chunk = MEAS_THREADS * MEAS_ITERS * 8;
     dim3 grid((zyx + chunk - 1) / chunk, (unsigned)T);
     { ProfScope ps_(K_MEASURE, st); hipLaunchKernelGGL((measure_kernel<NC, COORDS, 8>), grid, dim3(MEAS_THREADS), 0, st, img, labels, zyx, C,
-                       c0, Y, X, L, a); }
+                       c0, Y, X, L, a, frame_max); }
   } else {
     unsigned chunk = MEAS_THREADS * MEAS_ITERS;
     dim3 grid((zyx + chunk - 1) / chunk, (unsigned)T);
     { ProfScope ps_(K_MEASURE, st); hipLaunchKernelGGL((measure_kernel<NC, COORDS, 1>), grid, dim3(MEAS_THREADS), 0, st, img, labels, zyx, C,
-                       c0, Y, X, L, a); }
+                       c0, Y, X, L, a, frame_max); }
   }
   IAP_LAUNCH_CHECK();
   return IAP_OK;
@@ -251,8 +266,8 @@ static int launch_measure(const uint16_t* img, const uint16_t* labels, int64_t T
 
 using namespace iap;
 
-extern "C" int iap_measure_labels_u16(const uint16_t* img, const uint16_t* labels, int64_t T, int C, int Z,
-                                      int Y, int X, int L, uint64_t* acc, void* stream) {
+static int measure_labels(const uint16_t* img, const uint16_t* labels, int64_t T, int C, int Z, int Y, int X, int L,
+                          uint64_t* acc, uint32_t* frame_max, void* stream) {
   IAP_REQUIRE(img && labels && acc, IAP_E_ARG, "iap_measure_labels_u16: null pointer");
   IAP_REQUIRE(T > 0 && C > 0 && Z > 0 && Y > 0 && X > 0 && L > 0, IAP_E_ARG,
               "iap_measure_labels_u16: non-positive size (T=%lld C=%d Z=%d Y=%d X=%d L=%d)", (long long)T, C,
@@ -266,6 +281,7 @@ extern "C" int iap_measure_labels_u16(const uint16_t* img, const uint16_t* label
               "iap_measure_labels_u16: img/labels must be 16-byte and acc 8-byte aligned");
   hipStream_t st = as_stream(stream);
   IAP_HIP(hipMemsetAsync(acc, 0, (size_t)T * L * (4 + C) * sizeof(uint64_t), st));
+  if (frame_max) IAP_HIP(hipMemsetAsync(frame_max, 0, (size_t)T * sizeof(uint32_t), st));
   // channel groups of <= 4 keep every accumulator in registers; the first group also
   // carries count and coordinate sums.
   for (int c0 = 0; c0 < C; c0 += 4) {
@@ -274,8 +290,8 @@ extern "C" int iap_measure_labels_u16(const uint16_t* img, const uint16_t* label
     bool first = c0 == 0;
 #define IAP_MEAS_CASE(N)                                                                                  \
   case N:                                                                                                 \
-    rc = first ? launch_measure<N, true>(img, labels, T, C, c0, Z, Y, X, L, acc, st)                      \
-               : launch_measure<N, false>(img, labels, T, C, c0, Z, Y, X, L, acc, st);                    \
+    rc = first ? launch_measure<N, true>(img, labels, T, C, c0, Z, Y, X, L, acc, frame_max, st)           \
+               : launch_measure<N, false>(img, labels, T, C, c0, Z, Y, X, L, acc, nullptr, st);           \
     break;
     switch (nc) {
       IAP_MEAS_CASE(1)
@@ -289,6 +305,18 @@ extern "C" int iap_measure_labels_u16(const uint16_t* img, const uint16_t* label
     if (rc) return rc;
   }
   return IAP_OK;
+}
+
+extern "C" int iap_measure_labels_u16(const uint16_t* img, const uint16_t* labels, int64_t T, int C, int Z,
+                                      int Y, int X, int L, uint64_t* acc, void* stream) {
+  return measure_labels(img, labels, T, C, Z, Y, X, L, acc, nullptr, stream);
+}
+
+extern "C" int iap_measure_labels_max_u16(const uint16_t* img, const uint16_t* labels, int64_t T, int C, int Z,
+                                          int Y, int X, int L, uint64_t* acc, uint32_t* frame_max, void* stream) {
+  IAP_REQUIRE(frame_max && (reinterpret_cast<uintptr_t>(frame_max) & 3u) == 0, IAP_E_ARG,
+              "iap_measure_labels_max_u16: frame_max must be a 4-byte aligned device pointer");
+  return measure_labels(img, labels, T, C, Z, Y, X, L, acc, frame_max, stream);
 }
 
 extern "C" int iap_measure_finalize(const uint64_t* acc, int64_t T, int L, int C, int64_t* area, double* mean,

@@ -56,9 +56,26 @@ def max_label(labels: torch.Tensor) -> int:
     return int(out.item())
 
 
+PROVISIONAL_LABELS = 8192   # accumulator rows of a measurement whose label range is not known beforehand
+
+
+def _measure_call(img, labels, L, acc, frame_max=None):
+    t, c, z, y, x = img.shape
+    lib = _lib.load()
+    if frame_max is None:
+        _lib.check(lib.iap_measure_labels_u16(img.data_ptr(), labels.data_ptr(), t, c, z, y, x, L, acc.data_ptr(),
+                                              _stream()), "iap_measure_labels_u16")
+    else:
+        _lib.check(lib.iap_measure_labels_max_u16(img.data_ptr(), labels.data_ptr(), t, c, z, y, x, L, acc.data_ptr(),
+                                                  frame_max.data_ptr(), _stream()), "iap_measure_labels_max_u16")
+
+
 def measure_accumulate(img: torch.Tensor, labels: torch.Tensor, n_labels: int | None = None) -> torch.Tensor:
     """img u16 (T,C,Z,Y,X), labels u16 (T,Z,Y,X) -> exact integer accumulators
-    int64 (T, L, 4+C): count, sum_z, sum_y, sum_x, sum_I[c]  (analysis.py:80-98,164-173)."""
+    int64 (T, L, 4+C): count, sum_z, sum_y, sum_x, sum_I[c]  (analysis.py:80-98,164-173).
+    L = ``n_labels`` or, when that is not given, largest label + 1 (the reference's np.unique(mask) range): the
+    measuring pass itself reports the largest label, so the label stack is not read a second time for it; only a
+    stack with more than PROVISIONAL_LABELS ids is measured again with the range it turned out to need."""
     _need_cuda(img, labels)
     _u16(img)
     _u16(labels)
@@ -67,12 +84,19 @@ def measure_accumulate(img: torch.Tensor, labels: torch.Tensor, n_labels: int | 
     t, c, z, y, x = img.shape
     if tuple(labels.shape) != (t, z, y, x):
         raise ValueError(f"labels shape {tuple(labels.shape)} does not match image stack {(t, z, y, x)}")
-    L = int(n_labels) if n_labels is not None else max_label(labels) + 1
-    acc = torch.empty((t, L, 4 + c), dtype=torch.int64, device=img.device)
-    lib = _lib.load()
-    _lib.check(lib.iap_measure_labels_u16(img.data_ptr(), labels.data_ptr(), t, c, z, y, x, L, acc.data_ptr(),
-                                          _stream()), "iap_measure_labels_u16")
-    return acc
+    if n_labels is not None:
+        acc = torch.empty((t, int(n_labels), 4 + c), dtype=torch.int64, device=img.device)
+        _measure_call(img, labels, int(n_labels), acc)
+        return acc
+    acc = torch.empty((t, PROVISIONAL_LABELS, 4 + c), dtype=torch.int64, device=img.device)
+    fmax = torch.empty(t, dtype=torch.int32, device=img.device)
+    _measure_call(img, labels, PROVISIONAL_LABELS, acc, fmax)
+    L = int(fmax.max().item()) + 1
+    if L > PROVISIONAL_LABELS:
+        acc = torch.empty((t, L, 4 + c), dtype=torch.int64, device=img.device)
+        _measure_call(img, labels, L, acc)
+        return acc
+    return acc[:, :L].contiguous()
 
 
 def measure_finalize(acc: torch.Tensor):
@@ -450,11 +474,10 @@ def hot_path(stack: torch.Tensor, labels: torch.Tensor, threshold: float, reg_ch
     ``reg_ref='previous'`` needs the registered previous frame and is not offered block-wise."""
     _need_cuda(stack, labels)
     t, c, z, y, x = stack.shape
-    L = int(n_labels) if n_labels is not None else max_label(labels) + 1
     levels, _ = bg_smo_levels(stack, threshold, sigma=sigma, size=size)
     if not tblock or tblock >= t:
         reg, shifts = im_reg(stack, reg_channel, reg_ref, upsample=upsample, batch=batch, out=out, sub2=levels)
-        return measure_finalize(measure_accumulate(reg, labels, L)), shifts, levels
+        return measure_finalize(measure_accumulate(reg, labels, n_labels)), shifts, levels
     if reg_ref == "previous":
         raise ValueError("time blocks cannot run reg_ref='previous' (serial through the registered frames)")
     planes = lowered_channel_mip(stack, reg_channel, levels)                       # (T, Y, X)
@@ -463,17 +486,26 @@ def hot_path(stack: torch.Tensor, labels: torch.Tensor, threshold: float, reg_ch
                        out=scratch.view(t, 1, 1, y, x))
     del scratch
     lv = levels.view(t, c * z)
-    acc = torch.empty((t, L, 4 + c), dtype=torch.int64, device=stack.device)
     buf = out if out is not None else torch.empty((tblock,) + tuple(stack.shape[1:]), dtype=torch.uint16, device=stack.device)
     lib = _lib.load()
-    for t0 in range(0, t, tblock):
-        t1 = min(t, t0 + tblock)
-        nb = t1 - t0
-        _lib.check(lib.iap_apply_shift_sub_u16(stack[t0:t1].data_ptr(), buf.data_ptr(), nb, c * z, y, x,
-                                               shifts[t0:t1].data_ptr(), lv[t0:t1].data_ptr(), _stream()),
-                   "iap_apply_shift_sub_u16")
-        _lib.check(lib.iap_measure_labels_u16(buf.data_ptr(), labels[t0:t1].data_ptr(), nb, c, z, y, x, L,
-                                              acc[t0:t1].data_ptr(), _stream()), "iap_measure_labels_u16")
+
+    def blocks(L, fmax):
+        acc = torch.empty((t, L, 4 + c), dtype=torch.int64, device=stack.device)
+        for t0 in range(0, t, tblock):
+            t1 = min(t, t0 + tblock)
+            _lib.check(lib.iap_apply_shift_sub_u16(stack[t0:t1].data_ptr(), buf.data_ptr(), t1 - t0, c * z, y, x,
+                                                   shifts[t0:t1].data_ptr(), lv[t0:t1].data_ptr(), _stream()),
+                       "iap_apply_shift_sub_u16")
+            _measure_call(buf[: t1 - t0], labels[t0:t1], L, acc[t0:t1], None if fmax is None else fmax[t0:t1])
+        return acc
+
+    if n_labels is not None:
+        return measure_finalize(blocks(int(n_labels), None)), shifts, levels
+    fmax = torch.empty(t, dtype=torch.int32, device=stack.device)
+    acc = blocks(PROVISIONAL_LABELS, fmax)
+    L = int(fmax.max().item()) + 1
+    # more ids than the provisional table holds: the blocks are warped and measured once more (as rare as such masks)
+    acc = blocks(L, None) if L > PROVISIONAL_LABELS else acc[:, :L].contiguous()
     return measure_finalize(acc), shifts, levels
 
 

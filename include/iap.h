@@ -168,6 +168,14 @@ int iap_measure_labels_u16(const uint16_t* img, const uint16_t* labels,
                            int64_t T, int C, int Z, int Y, int X, int L,
                            uint64_t* acc, void* stream);
 
+/* The same pass, also reporting frame_max u32 [T] (zeroed by the call): the largest label value of every
+ * frame, labels >= L included.  It lets a caller that does not know the label range (the reference takes it from
+ * np.unique(mask), analysis.py:80) measure with a provisional L and repeat the call only when max(frame_max) >= L,
+ * instead of reading the label stack once more beforehand (iap_max_u16). */
+int iap_measure_labels_max_u16(const uint16_t* img, const uint16_t* labels,
+                               int64_t T, int C, int Z, int Y, int X, int L,
+                               uint64_t* acc, uint32_t* frame_max, void* stream);
+
 /* Accumulators -> tables (device): area i64 [T][L]; mean f64 [T][L][C] = (f64)sum/(f64)count
  * (numpy nanmean(where=) semantics, bit-exact); centroid f64 [T][L][3] (z,y,x);
  * centroid_rne i64 [T][L][3] (round-half-even, Python round()).  Rows with count 0: all 0. */

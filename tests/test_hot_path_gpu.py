@@ -141,3 +141,19 @@ def test_frames_without_labels(dev):
     lab[:] = 0
     (area, _, _, _), _, _ = ops.hot_path(d, ops.to_device_u16(lab, dev), THR, reg_ref="first", upsample=False)
     assert area.shape == (t, 1) and (area.cpu().numpy() == y * x).all()
+
+
+@pytest.mark.parametrize("tblock", [None, 2])
+def test_more_ids_than_the_provisional_table(dev, tblock, monkeypatch):
+    """label range not given and larger than the provisional accumulator table: the measurement is repeated with
+    the range the first pass reported (whole-stack and block-wise forms), tables as with the range given"""
+    monkeypatch.setattr(ops, "PROVISIONAL_LABELS", 4)
+    t, y, x = 4, 64, 96
+    st, _ = synth.make_stack(t, 2, 1, y, x, n_cells=5, integer_drift=True, seed=2)
+    lab = _labels(t, 1, y, x, 9)
+    d, dl = ops.to_device_u16(st, dev), ops.to_device_u16(lab, dev)
+    got = ops.hot_path(d, dl, THR, reg_ref="first", upsample=False, tblock=tblock)
+    exp = ops.hot_path(d, dl, THR, reg_ref="first", upsample=False, tblock=tblock, n_labels=int(lab.max()) + 1)
+    for a, b in zip(got[0], exp[0]):
+        assert torch.equal(a, b)
+    assert got[0][0].shape == (t, int(lab.max()) + 1)

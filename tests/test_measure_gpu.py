@@ -2,6 +2,7 @@
 Reference semantics: analysis.py:80-98 (mean), :164-173 (centroid), experiments.py:200-201 (area)."""
 import numpy as np
 import pytest
+import torch
 
 from oracle import ref_path as O
 from imageanalysis_pipeline_amd import synth
@@ -128,3 +129,21 @@ def test_bad_arguments_raise(dev):
         ops.measure_accumulate(img, lab)
     with pytest.raises(TypeError):
         ops.measure_accumulate(img.view(torch.int16), lab)
+
+
+@pytest.mark.parametrize("provisional", [4, 64, 8192])
+def test_label_range_found_by_the_measuring_pass(dev, provisional, monkeypatch):
+    """n_labels not given: the pass reports the largest label itself; stacks with more ids than the provisional
+    table are measured again -- same tables either way, and the same as with the range given"""
+    from imageanalysis_pipeline_amd import ops
+    monkeypatch.setattr(ops, "PROVISIONAL_LABELS", provisional)
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 65536, size=(3, 2, 1, 64, 96)).astype(np.uint16)
+    lab = np.stack([synth.make_labels(64, 96, 10, seed=s)[None] for s in range(3)])
+    lab[2][lab[2] == 3] = 40          # one frame reaches further than the others
+    lab[1] = 0                        # one frame has no label at all
+    d, dl = ops.to_device_u16(img, dev), ops.to_device_u16(lab, dev)
+    acc = ops.measure_accumulate(d, dl)
+    assert acc.shape == (3, 41, 6)
+    assert torch.equal(acc, ops.measure_accumulate(d, dl, 41))
+    _check(img, lab, dev)
