@@ -135,10 +135,9 @@ class Path:
         if self.two_pass:
             if self.bg is None:
                 self.bg = torch.empty_like(self.raw)
-            n_labels = ops.max_label(self.labels) + 1
             _, self.levels, _ = ops.bg_smo(self.raw, self.thr, out=self.bg)
             _, self.shifts = ops.im_reg(self.bg, 0, self.reg_ref, upsample=True, batch=self.batch, out=self.reg)
-            self.tables = ops.measure_finalize(ops.measure_accumulate(self.reg, self.labels, n_labels))
+            self.tables = ops.measure_finalize(ops.measure_accumulate(self.reg, self.labels))
         else:
             self.tables, self.shifts, self.levels = ops.hot_path(self.raw, self.labels, self.thr, 0, self.reg_ref,
                                                                  batch=self.batch, out=self.reg, tblock=self.tblock or None)
@@ -428,7 +427,7 @@ def main():
             "config": {"workload": f"{args.workload}: one FOV per GPU, T={t} C={c} Z={z} {y}x{x} uint16, sub-pixel drift, "
                                    f"{n_cells or 5041} labels/frame, reg_ref={args.reg_ref}"
                                    + (f", registered and measured {tblock} frames at a time" if tblock else ""),
-                       "stages": "max_label + bg_smo + im_reg(estimate+apply) + measure_labels", "parallelism": f"fov-shard x{world}",
+                       "stages": "bg_smo + im_reg(estimate+apply) + measure_labels (label range found by the measuring pass)", "parallelism": f"fov-shard x{world}",
                        "bg_subtraction": "written as a stack of its own, then registered" if args.two_pass else
                                          "applied on load by the registration kernels (same bits, no intermediate stack)"},
             "hbm_frac_end_to_end": value * 1e6 / world * total_bpp / HBM_PEAK,
