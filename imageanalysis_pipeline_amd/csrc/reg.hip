@@ -1834,22 +1834,6 @@ static int reg_ref_spectrum(const RegPlan& p, RegWs& w, const void* ref, int kin
   return launch_cols_ref(p, w.Q, 0, w.refspec, 0, w.gscale, 1, w.tw_y, st);
 }
 
-// Workgroups of upsample_partial_kernel the current device holds at once.
-static int upsample_capacity() {
-  static int cap[64] = {0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1024;
-  if (!cap[dev]) {
-    int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, upsample_partial_kernel, 256, 0) != hipSuccess || per_cu < 1)
-      per_cu = 2;
-    if (const char* e = getenv("IAP_UP_WGS")) per_cu = std::max(1, std::min(per_cu, atoi(e)));
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-    cap[dev] = per_cu * cus;
-  }
-  return cap[dev];
-}
-
 // The reference of an estimate: w.refspec (default), one spectrum per frame (gref/gscale, channel-shift pairs), or
 // the half ROW spectrum of one reference plane (ref_rows: the serial 'previous' chain, cols_fused_kernel).
 struct RegRef {
@@ -1883,10 +1867,14 @@ static int reg_estimate_batch(const RegPlan& p, RegWs& w, const uint16_t* mov, l
                        p.row_blocks, p.Py, p.Px, w.coarse, shifts, 1);
   }
   if (up) {
-    // row chunks (multiples of 4 rows) sized so that the whole launch is resident at once
-    int nuc = std::min(p.nuc, std::max(1, upsample_capacity() / (n * p.ncg)));
-    const int ub = (((p.Py + nuc - 1) / nuc) + 3) & ~3;
-    nuc = (p.Py + ub - 1) / ub;
+    // Row chunks of a size that depends on the plane alone: an 8th of the rows from 2048 rows on (64 frames x 2 column
+    // groups x 8 chunks = 1024 workgroups, measured 207 us against 200 for 4 chunks and 215-250 for 6, 10, 12, 16),
+    // a 16th below.  The partial sums are float: were the chunking sized by the number of frames in the launch, a
+    // frame's shift would depend (at the 1e-4 px level) on how many others were estimated with it -- on the workspace
+    // the caller happened to pass, or on how a stack is split over ranks.
+    const int parts = p.Py >= 2048 ? 8 : 16;
+    const int ub = std::max(UP_UB_MIN, ((p.Py + parts - 1) / parts + 3) & ~3);
+    const int nuc = (p.Py + ub - 1) / ub;
     const int nch = p.ncg * nuc, nyb = (p.Py + 255) / 256;
     { ProfScope ps_(K_OTHER, st);
       hipLaunchKernelGGL(upsample_tables_kernel, dim3((p.Py + p.Wp + 255) / 256, n), dim3(256), 0, st, p.Py, p.Px, p.Wp,

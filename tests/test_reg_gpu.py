@@ -84,6 +84,26 @@ def test_estimate_full_size_2048(dev):
     assert np.abs(got + dr).max() < 0.05
 
 
+@pytest.mark.parametrize("shape,n", [((2048, 2048), 7), ((1024, 512), 40), ((512, 192), 70)])
+def test_estimate_does_not_depend_on_the_launch_group(dev, shape, n):
+    """the column kernel runs as persistent workgroups over (frame, tile) items -- several items per workgroup at
+    these sizes, with the next item's tile prefetched: every frame's shift equals the one it gets alone and in
+    groups of other sizes, bit for bit"""
+    from imageanalysis_pipeline_amd import ops
+    y, x = shape
+    st, _ = _stack(n, 1, 1, y, x, False, cells=40, seed=n)
+    planes = ops.to_device_u16(st[:, 0, 0], dev)
+    whole = ops.estimate_shifts(planes[0], planes, batch=n)
+    for b in (1, 3, 64):
+        ops._ws_cache.clear()      # the scratch tensor only grows: without this the library would keep the larger group
+        assert torch.equal(ops.estimate_shifts(planes[0], planes, batch=b), whole), f"batch {b}"
+    alone = torch.cat([ops.estimate_shifts(planes[0], planes[f:f + 1]) for f in (0, n // 2, n - 1)])
+    assert torch.equal(alone, whole[[0, n // 2, n - 1]])
+    f = n - 1
+    exp = O.phase_shift(st[0, 0, 0], st[f, 0, 0])
+    assert np.abs(whole[f].cpu().numpy() - np.array(exp)).max() < SHIFT_TOL
+
+
 def _check_apply(img, shifts, dev):
     from imageanalysis_pipeline_amd import ops
     t = img.shape[0]
