@@ -12,7 +12,9 @@ rank, world = dist.get_rank(), dist.get_world_size()
 dev = torch.device("cuda", rank % torch.cuda.device_count())
 torch.cuda.set_device(dev)
 ok_all = True
-for (t, c, z, y, x) in ((7, 2, 1, 128, 256), (5, 2, 3, 128, 128), (2, 2, 1, 128, 128)):   # the last: fewer frames than ranks
+# the third: fewer frames than ranks; the last: full-size planes, where the launch groups of the ranks and of the
+# single process differ most (shifts do not depend on them: DESIGN.md section 2)
+for (t, c, z, y, x) in ((7, 2, 1, 128, 256), (5, 2, 3, 128, 128), (2, 2, 1, 128, 128), (10, 1, 1, 2048, 2048)):
     st, _ = synth.make_stack(t, c, z, y, x, n_cells=8, integer_drift=False, seed=21)
     lab = np.stack([np.stack([synth.make_labels(y, x, 8, seed=21)] * z)] * t)
     thr = ops.smo_threshold((y, x), device=dev)
