@@ -157,3 +157,27 @@ def test_more_ids_than_the_provisional_table(dev, tblock, monkeypatch):
     for a, b in zip(got[0], exp[0]):
         assert torch.equal(a, b)
     assert got[0][0].shape == (t, int(lab.max()) + 1)
+
+
+def test_side_streams_give_the_same_bits(dev):
+    """the library enqueues on the stream it is given and never synchronises: two FOVs processed concurrently on
+    two side streams (each with its own scratch) equal their runs on the default stream"""
+    t, c, y, x = 6, 2, 128, 160
+    fovs = []
+    for seed in (11, 12):
+        st, _ = synth.make_stack(t, c, 1, y, x, n_cells=9, integer_drift=False, seed=seed)
+        fovs.append((ops.to_device_u16(st, dev), ops.to_device_u16(_labels(t, 1, y, x, 6, seed=seed), dev)))
+    ref = [ops.hot_path(d, dl, THR) for d, dl in fovs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev) for _ in fovs]
+    got = []
+    for s, (d, dl) in zip(streams, fovs):
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            got.append(ops.hot_path(d, dl, THR))
+    for s in streams:
+        s.synchronize()
+    for g, r in zip(got, ref):
+        assert torch.equal(g[1], r[1]) and torch.equal(g[2], r[2])
+        for a, b in zip(g[0], r[0]):
+            assert torch.equal(a, b)
