@@ -118,7 +118,7 @@ def make_device_stack(t, c, z, y, x, n_cells, device, seed=0, subpixel=True, lab
 class Path:
     """The hot path on one resident FOV."""
 
-    def __init__(self, stack, labels, reg_ref="mean", batch=64, two_pass=False, tblock=0):
+    def __init__(self, stack, labels, reg_ref="mean", batch=None, two_pass=False, tblock=0):
         from imageanalysis_pipeline_amd import ops
         self.ops = ops
         self.raw, self.labels = stack, labels
@@ -290,7 +290,7 @@ def main():
     ap.add_argument("--tblock", type=int, default=-1, help="frames registered + measured at a time (0: whole stack)")
     ap.add_argument("--reg-ref", default="mean", choices=["first", "mean", "previous"],
                     help="reference frame of the registration; 'mean' is the reference's default (core.py:77) and what its notebook passes")
-    ap.add_argument("--batch", type=int, default=64, help="frames per registration launch group")
+    ap.add_argument("--batch", type=int, default=0, help="frames per registration launch group (0: the library wrapper's choice, 64 at 2048^2)")
     ap.add_argument("--two-pass", action="store_true", help="write the background-subtracted stack, then register it")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -337,7 +337,7 @@ def main():
     if args.two_pass or args.reg_ref == "previous":
         tblock = 0
     stack, labels, _ = make_device_stack(t, c, z, y, x, n_cells, dev, seed=rank)
-    path = Path(stack, labels, args.reg_ref, args.batch, args.two_pass, tblock)
+    path = Path(stack, labels, args.reg_ref, args.batch or None, args.two_pass, tblock)
     lib = _lib.load()
 
     def one_step():

@@ -271,7 +271,20 @@ def gauss_blur(planes: torch.Tensor, ksize=(15, 15), sigma: float = 5.0) -> torc
 
 # ----------------------------------------------------------------------------- registration
 
-DEFAULT_REG_BATCH = 64   # frames per launch group: C2 estimate 17.5 / 13.7 / 13.4 / 12.8 / 12.65 ms at 4 / 8 / 16 / 32 / 64
+DEFAULT_REG_BATCH = 64   # frames per launch group at 2048^2: C2 estimate 17.5 / 13.7 / 13.4 / 12.8 / 12.65 ms at 4 / 8 / 16 / 32 / 64
+REG_GROUP_BYTES = 2 << 30   # ... and, with ``batch=None``, as many frames as this much workspace holds (smaller planes:
+                            # larger groups, fewer launches -- a 100-frame stack of 512^2 is one group; never fewer than 64)
+
+
+def _reg_batch(batch, frames, ws_bytes_of):
+    """frames per registration launch group: the caller's, or what REG_GROUP_BYTES of workspace holds"""
+    frames = max(1, int(frames))
+    if batch is not None and int(batch) > 0:
+        return max(1, min(int(batch), frames))
+    b = min(frames, DEFAULT_REG_BATCH)
+    while b < frames and ws_bytes_of(min(frames, 2 * b)) <= REG_GROUP_BYTES:
+        b = min(frames, 2 * b)
+    return b
 
 
 def mip(stack: torch.Tensor) -> torch.Tensor:
@@ -314,7 +327,7 @@ def _reg_flags(upsample: bool, normalize: bool) -> int:
 
 
 def estimate_shifts(ref: torch.Tensor, mov: torch.Tensor, upsample: bool = True, normalize: bool = False,
-                    batch: int = DEFAULT_REG_BATCH) -> torch.Tensor:
+                    batch: int | None = None) -> torch.Tensor:
     """(dy, dx) to apply to each moving plane so that it overlays ``ref`` (replaces
     StackReg.register, utility.py:340).  ref: (Y, X) u16 / int32-sums / f32; mov: (n, Y, X) u16.
     Returns a float64 (n, 2) device tensor."""
@@ -329,7 +342,7 @@ def estimate_shifts(ref: torch.Tensor, mov: torch.Tensor, upsample: bool = True,
     if tuple(ref.shape) != (y, x):
         raise ValueError("ref and mov plane shapes differ")
     lib = _lib.load()
-    nb = lib.iap_reg_ws_bytes(y, x, 1, max(1, min(batch, n)))
+    nb = lib.iap_reg_ws_bytes(y, x, 1, _reg_batch(batch, n, lambda b: lib.iap_reg_ws_bytes(y, x, 1, b)))
     if nb == 0:
         raise ValueError(f"registration needs planes of at least 64x64, got {y}x{x}")
     ws = _workspace(nb, mov.device)
@@ -341,7 +354,7 @@ def estimate_shifts(ref: torch.Tensor, mov: torch.Tensor, upsample: bool = True,
 
 
 def estimate_pair_shifts(ref: torch.Tensor, mov: torch.Tensor, upsample: bool = True, normalize: bool = False,
-                         batch: int = DEFAULT_REG_BATCH) -> torch.Tensor:
+                         batch: int | None = None) -> torch.Tensor:
     """(dy, dx) for n independent pairs: ref (n, Y, X) u16 against mov (n, Y, X) u16, plane by plane.  Both may
     be strided views along n (planes themselves contiguous).  Returns float64 (n, 2) on the device."""
     for a in (ref, mov):          # strided along n is fine here, so no _need_cuda (it insists on contiguity)
@@ -357,7 +370,7 @@ def estimate_pair_shifts(ref: torch.Tensor, mov: torch.Tensor, upsample: bool = 
         if a.stride(2) != 1 or a.stride(1) != x or (n > 1 and a.stride(0) < y * x):
             raise ValueError("planes must be contiguous (a stride along n is allowed)")
     lib = _lib.load()
-    nb = lib.iap_reg_pairs_ws_bytes(y, x, max(1, min(batch, n)))
+    nb = lib.iap_reg_pairs_ws_bytes(y, x, _reg_batch(batch, n, lambda b: lib.iap_reg_pairs_ws_bytes(y, x, b)))
     if nb == 0:
         raise ValueError(f"registration needs planes of at least 64x64, got {y}x{x}")
     ws = _workspace(nb, mov.device)
@@ -422,7 +435,7 @@ def apply_shifts(stack: torch.Tensor, shifts: torch.Tensor, sub2: torch.Tensor |
 
 
 def im_reg(stack: torch.Tensor, reg_channel: int = 0, reg_ref: str = "mean", upsample: bool = True,
-           normalize: bool = False, batch: int = DEFAULT_REG_BATCH, out: torch.Tensor | None = None,
+           normalize: bool = False, batch: int | None = None, out: torch.Tensor | None = None,
            sub2: torch.Tensor | None = None):
     """utility.py:274-430 (translation) on a resident stack u16 (T, C, Z, Y, X).
     Returns (registered stack, shifts f64 (T, 2)).  ``sub2`` (int32, one per plane: ``bg_smo_levels``'s med2):
@@ -436,7 +449,7 @@ def im_reg(stack: torch.Tensor, reg_channel: int = 0, reg_ref: str = "mean", ups
         raise ValueError(f"{reg_ref} is not valid. Please only put {list(REF_MODES)}")
     t, c, z, y, x = stack.shape
     lib = _lib.load()
-    nb = lib.iap_reg_ws_bytes(y, x, z, max(1, min(batch, t)))
+    nb = lib.iap_reg_ws_bytes(y, x, z, _reg_batch(batch, t, lambda b: lib.iap_reg_ws_bytes(y, x, z, b)))
     if nb == 0:
         raise ValueError(f"registration needs planes of at least 64x64, got {y}x{x}")
     ws = _workspace(nb, stack.device)
@@ -460,7 +473,7 @@ def im_reg(stack: torch.Tensor, reg_channel: int = 0, reg_ref: str = "mean", ups
 
 # ---------------------------------------------------------------- the whole path on one resident FOV
 def hot_path(stack: torch.Tensor, labels: torch.Tensor, threshold: float, reg_channel: int = 0, reg_ref: str = "mean",
-             upsample: bool = True, batch: int = DEFAULT_REG_BATCH, out: torch.Tensor | None = None,
+             upsample: bool = True, batch: int | None = None, out: torch.Tensor | None = None,
              tblock: int | None = None, n_labels: int | None = None, sigma: float = 0.0, size: int = 7):
     """core.py:99-112 + 328-330 on a resident FOV: smo_bg_sub -> im_reg -> per-label tables.  ``stack`` u16
     (T, C, Z, Y, X) raw, ``labels`` u16 (T, Z, Y, X).  Returns (tables, shifts, levels): tables as
