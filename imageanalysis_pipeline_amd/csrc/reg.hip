@@ -2094,8 +2094,9 @@ static int im_reg_impl(const uint16_t* in, uint16_t* out, int64_t T, int C, int 
   int rc = reg_check("iap_im_reg_u16", Y, X, p);
   if (rc) return rc;
   const long long px = (long long)Y * X;
-  IAP_REQUIRE(Z == 1 || (px % 8 == 0 && aligned16(in) && aligned16(out)), IAP_E_ALIGN,
-              "iap_im_reg_u16: z-stacks need 16-byte aligned buffers and Y*X %% 8 == 0");
+  // (planes of Y*X %% 8 != 0 pixels take the MIP kernel's scalar path, which needs no alignment)
+  IAP_REQUIRE(Z == 1 || px % 8 != 0 || (aligned16(in) && aligned16(out)), IAP_E_ALIGN,
+              "iap_im_reg_u16: z-stacks of planes with Y*X %% 8 == 0 need 16-byte aligned buffers");
   RegWs w;
   IAP_REQUIRE(carve(ws, ws_bytes, p, Z, w), IAP_E_WS, "iap_im_reg_u16: workspace of %zu bytes, need %zu", ws_bytes,
               iap_reg_ws_bytes(Y, X, Z, 1));

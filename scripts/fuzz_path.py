@@ -1,0 +1,103 @@
+"""Development aid (GPU): randomised differential run of the hot path against the oracle -- odd plane sizes, every
+reference mode, z-stacks, integer and sub-pixel drift, sparse and dense labels.
+    python scripts/fuzz_path.py [cases] [seed]
+Per case: background levels exact; shifts within 0.01 px (exact for integer drift without refinement); the registered
+stack within 1 count of the oracle's warp at the GPU's shifts; tables bit-exact for the GPU's registered stack."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from imageanalysis_pipeline_amd import ops, synth  # noqa: E402
+from oracle import ref_path as O  # noqa: E402
+
+
+def one(rng, dev, k):
+    y = int(rng.integers(64, 420))
+    x = int(rng.integers(64, 420))
+    if rng.random() < 0.3:
+        y, x = int(rng.choice([64, 128, 256, 512])), int(rng.choice([64, 128, 256, 512]))
+    t = int(rng.integers(1, 6))
+    c = int(rng.integers(1, 4))
+    z = int(rng.choice([1, 1, 1, 2, 3]))
+    mode = str(rng.choice(["first", "mean", "previous"]))
+    integer = bool(rng.random() < 0.4)
+    up = not integer or bool(rng.random() < 0.3)
+    regc = int(rng.integers(0, c))
+    ncell = int(rng.integers(3, 14))
+    st, _ = synth.make_stack(t, c, z, y, x, n_cells=ncell, integer_drift=integer, seed=int(rng.integers(1 << 30)))
+    lab2 = synth.make_labels(y, x, int(rng.integers(1, 40)), seed=int(rng.integers(1 << 30)))
+    lab = np.broadcast_to(lab2[None, None], (t, z, y, x)).copy()
+    if rng.random() < 0.2:
+        lab[rng.integers(0, t)] = 0
+    thr = 0.0455
+    desc = f"#{k} {t}x{c}x{z}x{y}x{x} {mode} regc={regc} integer={integer} up={up}"
+    d, dl = ops.to_device_u16(st, dev), ops.to_device_u16(lab, dev)
+    out = torch.empty_like(d)
+    tables, shifts, levels = ops.hot_path(d, dl, thr, reg_channel=regc, reg_ref=mode, upsample=up, out=out)
+    sh = shifts.cpu().numpy()
+    reg = ops.to_numpy_u16(out)
+    lv = levels.cpu().numpy().reshape(t, c, z)
+    bg = np.empty_like(st)
+    for f in range(t):
+        for ch in range(c):
+            for zz in range(z):
+                b, med2 = O.bg_smo(st[f, ch, zz], thr)[:2]
+                bg[f, ch, zz] = b
+                assert med2 == lv[f, ch, zz], (desc, "level", f, ch, zz, med2, lv[f, ch, zz])
+    _, es = O.im_reg_stack(bg, regc, mode, upsample=up)
+    err = np.abs(sh - es).max()
+    if integer and not up:
+        if err != 0:
+            # an exact tie is not a disagreement: against the mean of frames that sit at integer offsets a frame can
+            # lie half a pixel from the reference, and the correlation's two top values then differ by ~3e-7 relative
+            # (f64); float32 kernels may take either.  Accept the GPU's pick if the oracle's own surface has it
+            # within 1e-5 of its maximum.
+            assert mode == "mean" and err <= 1, (desc, "integer shifts", sh, es)
+            ref = bg[:, regc].astype(np.float64)
+            ref = (ref.max(axis=1) if z > 1 else ref[:, 0]).mean(axis=0)
+            for f in range(t):
+                if np.array_equal(sh[f], es[f]):
+                    continue
+                mov = bg[f, regc].max(axis=0) if z > 1 else bg[f, regc, 0]
+                cc = np.fft.ifft2(O.cross_power(O._crop_center(ref), O._crop_center(mov))).real
+                pick = cc[int(sh[f, 0]) % cc.shape[0], int(sh[f, 1]) % cc.shape[1]]
+                assert pick >= cc.max() * (1 - 1e-5), (desc, "integer shifts beyond a tie", f, sh[f], es[f], pick, cc.max())
+            print(f"   (tie: frames {[f for f in range(t) if not np.array_equal(sh[f], es[f])]} sit half a pixel from the mean)")
+            es = sh.copy()
+            err = 0.0
+    else:
+        assert err < 0.01, (desc, "shifts", sh, es)
+    worst = 0
+    for f in range(t):
+        for ch in range(c):
+            for zz in range(z):
+                exp = O.apply_shift(bg[f, ch, zz], sh[f, 0], sh[f, 1])
+                worst = max(worst, int(np.abs(reg[f, ch, zz].astype(np.int64) - exp.astype(np.int64)).max()))
+    assert worst <= 1, (desc, "warp", worst)
+    area, mean, cen, cen_r = (a.cpu().numpy() for a in tables)
+    for f in range(t):
+        e = O.measure_labels(reg[f, :, 0], lab[f, 0]) if z == 1 else O.measure_labels(reg[f], lab[f])
+        ids = e["ids"]
+        assert np.array_equal(np.nonzero(area[f])[0][1:], ids), (desc, "ids", f)
+        assert np.array_equal(area[f, ids], e["area"]), (desc, "area", f)
+        assert np.array_equal(mean[f, ids].view(np.uint64), e["mean"].view(np.uint64)), (desc, "mean", f)
+        sl = slice(0, 3) if z > 1 else slice(1, 3)
+        assert np.array_equal(cen_r[f, ids][:, sl], e["centroid_rne"]), (desc, "centroid", f)
+    print(f"ok {desc}: shift err {err:.2e} px, warp {worst}", flush=True)
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda:0")
+    for k in range(n):
+        one(rng, dev, k)
+    print("all", n, "cases agree")
+
+
+if __name__ == "__main__":
+    main()

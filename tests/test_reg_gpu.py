@@ -274,9 +274,13 @@ def test_bg_levels_then_subtract_on_load_equals_two_passes(dev):
     assert torch.equal(out.view(torch.int16), exp_out.view(torch.int16))
 
 
-def test_im_reg_zstack_mip(dev):
+@pytest.mark.parametrize("shape", [(128, 128), (94, 73), (71, 322)])
+def test_im_reg_zstack_mip(dev, shape):
+    """z-stacks register on the z-MIP; planes whose pixel count is not a multiple of 8 (every plane but the first
+    starts off a 16-byte boundary) take the MIP kernel's scalar path -- they were refused with IAP_E_ALIGN until a
+    randomised run (scripts/fuzz_path.py) met one"""
     from imageanalysis_pipeline_amd import ops
-    st, _ = _stack(4, 2, 3, 128, 128, True, seed=13)
+    st, _ = _stack(4, 2, 3, shape[0], shape[1], True, seed=13)
     out, sh = ops.im_reg(ops.to_device_u16(st, dev), reg_channel=0, reg_ref="first", upsample=False)
     eo, es = O.im_reg_stack(st, reg_channel=0, reg_ref="first", upsample=False)
     assert np.array_equal(sh.cpu().numpy(), es)
