@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IAP_LIB") or os.path.join(_HERE, "libiap_hip.so")
 
-_vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+_vp, _i32, _i64, _f32, _f64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_size_t
 
 # name -> (restype, argtypes); mirrors include/iap.h one to one
 SIGNATURES = {
@@ -23,7 +23,7 @@ SIGNATURES = {
     "iap_bg_smo_u16": (_i32, [_vp, _vp, _i64, _i32, _i32, _f32, _i32, _f32, _vp, _vp, _vp, _sz, _vp]),
     "iap_bg_const_u16": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "iap_bg_const_static_u16": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
-    "iap_gauss_blur_u16": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "iap_gauss_blur_u16": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _f64, _vp]),
     "iap_mip_u16": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp]),
     "iap_mip_sub_u16": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp]),
     "iap_reg_ws_bytes": (_sz, [_i32, _i32, _i32, _i32]),

@@ -927,7 +927,7 @@ extern "C" int iap_bg_const_static_u16(const uint16_t* in, uint16_t* out, int64_
 }
 
 extern "C" int iap_gauss_blur_u16(const uint16_t* in, uint16_t* out, int64_t n, int Y, int X, int kx, int ky,
-                                  float sigma, void* stream) {
+                                  double sigma, void* stream) {
   int rc = check_plane_args("iap_gauss_blur_u16", in, out, n, Y, X);
   if (rc) return rc;
   IAP_REQUIRE(in != out, IAP_E_ARG, "iap_gauss_blur_u16: in-place operation is not supported");
@@ -937,22 +937,27 @@ extern "C" int iap_gauss_blur_u16(const uint16_t* in, uint16_t* out, int64_t n, 
   hipStream_t st = as_stream(stream);
   // taps as cv2.getGaussianKernel(k, sigma, CV_32F); they ride to the kernel by value
   GaussTaps h;
-  auto fill = [](int k, float sg, float* t) {
+  auto fill = [](int k, double sg, float* t) {
     if (!(sg > 0) && k <= 7) {   // OpenCV's fixed table for small kernels without a sigma (small_gaussian_tab)
       static const float tab[4][4] = {{1.f, 0.f, 0.f, 0.f}, {0.5f, 0.25f, 0.f, 0.f}, {0.375f, 0.25f, 0.0625f, 0.f},
                                       {0.28125f, 0.21875f, 0.109375f, 0.03125f}};
       for (int i = 0; i <= (k - 1) / 2; ++i) t[i] = tab[(k - 1) / 2][i];
       return;
     }
-    double s = sg > 0 ? sg : 0.3 * ((k - 1) * 0.5 - 1) + 0.8;
-    double w[2 * GB_MAXR + 1], sum = 0;
+    // OpenCV 4.1.2 (the reference's pin), getGaussianKernel with CV_32F: float values of exp(scale2X x^2), their sum
+    // taken in index order in a double, normalised by a multiplication with the sum's reciprocal
+    const double s = sg > 0 ? sg : 0.3 * ((k - 1) * 0.5 - 1) + 0.8;
+    const double scale2x = -0.5 / (s * s);
+    float cf[2 * GB_MAXR + 1];
+    double sum = 0;
     for (int i = 0; i < k; ++i) {
-      double x = i - (k - 1) * 0.5;
-      w[i] = exp(-(x * x) / (2.0 * s * s));
-      sum += w[i];
+      const double x = i - (k - 1) * 0.5;
+      cf[i] = (float)exp(scale2x * x * x);
+      sum += cf[i];
     }
-    int r = (k - 1) / 2;
-    for (int i = 0; i <= r; ++i) t[i] = (float)(w[r + i] / sum);
+    sum = 1. / sum;
+    const int r = (k - 1) / 2;
+    for (int i = 0; i <= r; ++i) t[i] = (float)(cf[r + i] * sum);
   };
   fill(kx, sigma, h.x);
   fill(ky, sigma, h.y);

@@ -226,17 +226,23 @@ __global__ __launch_bounds__(256) void measure_finalize_kernel(
   }
 }
 
-__global__ __launch_bounds__(256) void max_u16_kernel(const uint16_t* __restrict__ p, long long n,
+// `head` leading elements (fewer than 8) bring the rest of the array to a 16-byte boundary; they and the tail are
+// read one by one
+__global__ __launch_bounds__(256) void max_u16_kernel(const uint16_t* __restrict__ p, long long n, int head,
                                                       unsigned* __restrict__ out) {
   unsigned m = 0;
-  long long nv = n >> 3;
+  const uint16_t* body = p + head;
+  const long long nb = n - head, nv = nb >> 3;
   long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
-    u16x8 v = load8(p + i * 8);
+    u16x8 v = load8(body + i * 8);
 #pragma unroll
     for (int k = 0; k < 8; ++k) m = max(m, (unsigned)v.v[k]);
   }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) m = max(m, (unsigned)p[nv * 8 + threadIdx.x]);
+  if (blockIdx.x == 0) {
+    if ((int)threadIdx.x < head) m = max(m, (unsigned)p[threadIdx.x]);
+    if (threadIdx.x < (nb & 7)) m = max(m, (unsigned)body[nv * 8 + threadIdx.x]);
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_down(m, o, 64));
   if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
@@ -335,14 +341,17 @@ extern "C" int iap_measure_finalize(const uint64_t* acc, int64_t T, int L, int C
 extern "C" int iap_max_u16(const uint16_t* labels, int64_t n, uint32_t* out, void* stream) {
   IAP_REQUIRE(labels && out, IAP_E_ARG, "iap_max_u16: null pointer");
   IAP_REQUIRE(n > 0, IAP_E_ARG, "iap_max_u16: n must be positive");
-  IAP_REQUIRE(aligned16(labels), IAP_E_ALIGN, "iap_max_u16: labels must be 16-byte aligned");
+  IAP_REQUIRE((reinterpret_cast<uintptr_t>(labels) & 1u) == 0, IAP_E_ALIGN, "iap_max_u16: labels must be 2-byte aligned");
   hipStream_t st = as_stream(stream);
   IAP_HIP(hipMemsetAsync(out, 0, sizeof(uint32_t), st));
-  long long nv = n >> 3;
+  // a frame of a stack whose planes are not a multiple of 8 pixels starts off a 16-byte boundary
+  int head = (int)(((16u - (unsigned)(reinterpret_cast<uintptr_t>(labels) & 15u)) & 15u) / 2u);
+  if (head > n) head = (int)n;
+  long long nv = (n - head) >> 3;
   unsigned blocks = (unsigned)((nv + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   if (blocks == 0) blocks = 1;
-  { ProfScope ps_(K_MAXLABEL, st); hipLaunchKernelGGL(max_u16_kernel, dim3(blocks), dim3(256), 0, st, labels, (long long)n, out); }
+  { ProfScope ps_(K_MAXLABEL, st); hipLaunchKernelGGL(max_u16_kernel, dim3(blocks), dim3(256), 0, st, labels, (long long)n, head, out); }
   IAP_LAUNCH_CHECK();
   return IAP_OK;
 }

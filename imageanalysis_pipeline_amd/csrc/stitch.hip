@@ -20,12 +20,12 @@ constexpr int MODE_SLOTS = 8;
 
 __global__ __launch_bounds__(256) void overlap_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
                                                       long long px, int na1, int nb1, long long mat_stride,
-                                                      unsigned* __restrict__ overlap) {
+                                                      unsigned* __restrict__ overlap, int vec) {
   const long long pair = blockIdx.y;
   const uint16_t* pa = a + pair * px;
   const uint16_t* pb = b + pair * px;
   unsigned* mat = overlap + pair * mat_stride;
-  const long long nv = px >> 3;
+  const long long nv = vec ? px >> 3 : 0;   // planes off a 16-byte boundary (odd sizes, frames of such stacks): all scalar
   unsigned zero = 0;
   // labels beyond the caller's bounds are dropped rather than written outside the matrix
   auto add = [&](unsigned key, unsigned run) {
@@ -50,13 +50,10 @@ __global__ __launch_bounds__(256) void overlap_kernel(const uint16_t* __restrict
     if (key == 0) zero += run;
     else add(key, run);
   }
-  if (blockIdx.x == 0) {  // pixels past the last whole vector
-    const long long t = nv * 8 + threadIdx.x;
-    if (t < px) {
-      const unsigned la = pa[t], lb = pb[t];
-      if ((la | lb) == 0) ++zero;
-      else add((la << 16) | lb, 1u);
-    }
+  for (long long t = nv * 8 + (long long)blockIdx.x * 256 + threadIdx.x; t < px; t += (long long)gridDim.x * 256) {
+    const unsigned la = pa[t], lb = pb[t];   // pixels past the last whole vector
+    if ((la | lb) == 0) ++zero;
+    else add((la << 16) | lb, 1u);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) zero += __shfl_down(zero, o, 64);
@@ -64,22 +61,21 @@ __global__ __launch_bounds__(256) void overlap_kernel(const uint16_t* __restrict
 }
 
 __global__ __launch_bounds__(256) void relabel_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
-                                                      long long px, const uint16_t* __restrict__ lut, int lut_stride) {
+                                                      long long px, const uint16_t* __restrict__ lut, int lut_stride,
+                                                      int vec) {
   const long long frame = blockIdx.y;
   const uint16_t* l = lut + frame * lut_stride;
   const uint16_t* pi = in + frame * px;
   uint16_t* po = out + frame * px;
-  const long long nv = px >> 3;
+  const long long nv = vec ? px >> 3 : 0;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
     u16x8 v = load8(pi + i * 8);
 #pragma unroll
     for (int k = 0; k < 8; ++k) v.v[k] = l[v.v[k]];
     store8(po + i * 8, v);
   }
-  if (blockIdx.x == 0) {
-    const long long t = nv * 8 + threadIdx.x;
-    if (t < px) po[t] = l[pi[t]];
-  }
+  for (long long t = nv * 8 + (long long)blockIdx.x * 256 + threadIdx.x; t < px; t += (long long)gridDim.x * 256)
+    po[t] = l[pi[t]];
 }
 
 __global__ __launch_bounds__(256) void mode_kernel(const uint16_t* __restrict__ masks, int T, long long px,
@@ -128,17 +124,16 @@ extern "C" int iap_label_overlap_u16(const uint16_t* a, const uint16_t* b, int64
   IAP_REQUIRE(n > 0 && px > 0, IAP_E_ARG, "iap_label_overlap_u16: non-positive size");
   IAP_REQUIRE(na_max >= 0 && na_max <= 65535 && nb_max >= 0 && nb_max <= 65535, IAP_E_ARG,
               "iap_label_overlap_u16: label bounds must be in 0..65535");
-  IAP_REQUIRE(aligned16(a) && aligned16(b) && (px % 8 == 0 || n == 1), IAP_E_ALIGN,
-              "iap_label_overlap_u16: planes must be 16-byte aligned (px a multiple of 8 when n > 1)");
+  const int vec = aligned16(a) && aligned16(b) && (px % 8 == 0 || n == 1);   // else the kernel's scalar path
   IAP_REQUIRE(n <= 65535, IAP_E_UNSUPPORTED, "iap_label_overlap_u16: n must be <= 65535");
   hipStream_t st = as_stream(stream);
   const size_t mat = (size_t)(na_max + 1) * (nb_max + 1);
   IAP_HIP(hipMemsetAsync(overlap, 0, (size_t)n * mat * 4, st));
-  unsigned gx = (unsigned)std::min<int64_t>((px / 8 + 255) / 256, 1024);
+  unsigned gx = (unsigned)std::min<int64_t>(((vec ? px / 8 : px) + 255) / 256, 1024);
   if (gx == 0) gx = 1;
   { ProfScope ps_(K_OTHER, st);
     hipLaunchKernelGGL(overlap_kernel, dim3(gx, (unsigned)n), dim3(256), 0, st, a, b, (long long)px, na_max + 1, nb_max + 1,
-                       (long long)mat, (unsigned*)overlap); }
+                       (long long)mat, (unsigned*)overlap, vec); }
   IAP_LAUNCH_CHECK();
   return IAP_OK;
 }
@@ -147,14 +142,14 @@ extern "C" int iap_relabel_u16(const uint16_t* in, uint16_t* out, int64_t n, int
                                int lut_stride, void* stream) {
   IAP_REQUIRE(in && out && lut, IAP_E_ARG, "iap_relabel_u16: null pointer");
   IAP_REQUIRE(n > 0 && px > 0 && lut_stride >= 0, IAP_E_ARG, "iap_relabel_u16: bad size");
-  IAP_REQUIRE(aligned16(in) && aligned16(out) && (px % 8 == 0 || n == 1), IAP_E_ALIGN,
-              "iap_relabel_u16: planes must be 16-byte aligned (px a multiple of 8 when n > 1)");
+  const int vec = aligned16(in) && aligned16(out) && (px % 8 == 0 || n == 1);   // else the kernel's scalar path
   IAP_REQUIRE(n <= 65535, IAP_E_UNSUPPORTED, "iap_relabel_u16: n must be <= 65535");
   hipStream_t st = as_stream(stream);
-  unsigned gx = (unsigned)std::min<int64_t>((px / 8 + 255) / 256, 1024);
+  unsigned gx = (unsigned)std::min<int64_t>(((vec ? px / 8 : px) + 255) / 256, 1024);
   if (gx == 0) gx = 1;
   { ProfScope ps_(K_OTHER, st);
-    hipLaunchKernelGGL(relabel_kernel, dim3(gx, (unsigned)n), dim3(256), 0, st, in, out, (long long)px, lut, lut_stride); }
+    hipLaunchKernelGGL(relabel_kernel, dim3(gx, (unsigned)n), dim3(256), 0, st, in, out, (long long)px, lut, lut_stride,
+                       vec); }
   IAP_LAUNCH_CHECK();
   return IAP_OK;
 }

@@ -81,9 +81,11 @@ int iap_bg_const_static_u16(const uint16_t* in, uint16_t* out, int64_t n, int Y,
                             int r0, int c0, int r1, int c1, int32_t* bg_out, void* stream);
 
 /* utility.py:462 blur_img: cv2.GaussianBlur(im,(kx,ky),sigma).astype(uint16) semantics,
- * reflect-101 border, fp32 taps, round-half-even + saturate.  kx, ky odd, <= 63. */
+ * reflect-101 border, fp32 taps (OpenCV 4.1.2's getGaussianKernel, the reference's pin: environment.yml:15),
+ * round-half-even + saturate.  kx, ky odd, <= 63.  sigma is a double, as cv2's sigmaX: the taps are worked out
+ * in double from it. */
 int iap_gauss_blur_u16(const uint16_t* in, uint16_t* out, int64_t n, int Y, int X,
-                       int kx, int ky, float sigma, void* stream);
+                       int kx, int ky, double sigma, void* stream);
 
 /* ------------------------------------------------------------------ registration ----- */
 
@@ -217,6 +219,8 @@ int iap_masked_gather_u16(const uint16_t* mask, const int32_t* sq, const uint16_
  * iap_label_overlap_u16: cellpose.metrics._label_overlap for n plane pairs of px pixels:
  *   overlap[p][i][j] = #{a == i and b == j}, u32 [n][na_max+1][nb_max+1], zeroed by the call (labels
  *   above the bounds are ignored).  IoU = overlap / (row sum + column sum - overlap) is left to the host.
+ * (Planes that are not 16-byte aligned -- frames of a stack whose planes are not a multiple of 8 pixels -- are
+ * read pixel by pixel by iap_label_overlap_u16, iap_relabel_u16 and iap_max_u16 instead of being refused.)
  * iap_relabel_u16: out = lut[frame][in] (masks[i] = istitch[masks[i]], utility.py:724,735); lut_stride
  *   elements between the tables of consecutive frames (0: one table for all).
  * iap_label_mode_u16: master mask of utility.py:707-711: per pixel the most frequent non-zero label over T

@@ -169,16 +169,24 @@ _CV_SMALL_GAUSS = {
 
 
 def gauss_taps_cv(ksize: int, sigma: float) -> np.ndarray:
-    """cv2.getGaussianKernel(ksize, sigma, CV_32F): sigma<=0 -> 0.3*((k-1)*0.5-1)+0.8, except that OpenCV
-    takes odd sizes up to 7 with sigma <= 0 from a fixed table (its small_gaussian_tab: binomial-like
-    weights, e.g. 0.25 / 0.5 / 0.25 for 3 taps), not from the exponential."""
+    """cv2.getGaussianKernel(ksize, sigma, CV_32F) as OpenCV 4.1.2 computes it (the version the reference pins,
+    environment.yml:15; modules/imgproc/src/smooth.dispatch.cpp, getGaussianKernel): sigma <= 0 ->
+    0.3*((k-1)*0.5-1)+0.8, odd sizes up to 7 with sigma <= 0 from the fixed small_gaussian_tab; otherwise
+    t_i = exp(scale2X * x_i * x_i) with scale2X = -0.5 / sigma^2 in double, stored as float, summed (the float values,
+    in index order, in a double), and normalised by a multiplication with the reciprocal of the sum, rounded to float."""
     if sigma <= 0 and ksize in _CV_SMALL_GAUSS:
         return np.asarray(_CV_SMALL_GAUSS[ksize], dtype=np.float32)
     if sigma <= 0:
         sigma = 0.3 * ((ksize - 1) * 0.5 - 1) + 0.8
-    x = np.arange(ksize, dtype=np.float64) - (ksize - 1) * 0.5
-    w = np.exp(-(x * x) / (2.0 * sigma * sigma))
-    return (w / w.sum()).astype(np.float32)
+    scale2x = -0.5 / (float(sigma) * float(sigma))
+    cf = np.empty(ksize, dtype=np.float32)
+    total = 0.0
+    for i in range(ksize):
+        x = i - (ksize - 1) * 0.5
+        cf[i] = np.float32(np.exp(scale2x * x * x))
+        total += float(cf[i])
+    inv = 1.0 / total
+    return np.array([np.float32(float(c) * inv) for c in cf], dtype=np.float32)
 
 
 def _sym_fir_f32(a: np.ndarray, w: np.ndarray, axis: int) -> np.ndarray:

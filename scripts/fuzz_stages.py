@@ -1,0 +1,163 @@
+"""Development aid (GPU): randomised differential run of the single stages and the widening primitives against the
+oracle -- shapes, parameters and label statistics the fixed tests do not visit.
+    python scripts/fuzz_stages.py [cases] [seed]
+Bit-exact everywhere except the SMO image (2e-6, 3e-4 with sigma > 0)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from imageanalysis_pipeline_amd import ops, synth  # noqa: E402
+from oracle import ref_path as O  # noqa: E402
+
+
+def shape(rng, lo=16, hi=300):
+    return int(rng.integers(lo, hi)), int(rng.integers(lo, hi))
+
+
+def f_bg_smo(rng, dev):
+    y, x = shape(rng, 24)
+    n = int(rng.integers(1, 4))
+    base = int(rng.choice([0, 300, 5000, 60000]))
+    st, _ = synth.make_stack(n, 1, 1, y, x, n_cells=int(rng.integers(1, 9)), integer_drift=True,
+                             seed=int(rng.integers(1 << 30)))
+    img = np.clip(st[:, 0, 0].astype(np.int64) + base - 300, 0, 65535).astype(np.uint16)
+    thr = float(rng.choice([0.02, 0.0455, 0.1, 0.5]))
+    out, med2, nbg = ops.bg_smo(ops.to_device_u16(img, dev), thr)
+    for k in range(n):
+        eo, em, en, _ = O.bg_smo(img[k], thr)
+        # the mask may differ on pixels whose SMO value is within 2e-6 of the threshold; then the median can move
+        assert abs(int(nbg[k]) - en) <= max(2, en // 100000), ("bg count", y, x, thr, int(nbg[k]), en)
+        if int(nbg[k]) == en:
+            assert int(med2[k]) == em, ("bg level", y, x, thr, int(med2[k]), em)
+            assert np.array_equal(ops.to_numpy_u16(out[k]), eo), ("bg out", y, x, thr)
+    return f"bg_smo {n}x{y}x{x} thr={thr} base={base}"
+
+
+def f_blur(rng, dev):
+    y, x = shape(rng, 8)
+    ky, kx = int(rng.integers(0, 32)) * 2 + 1, int(rng.integers(0, 32)) * 2 + 1
+    sig = float(rng.choice([0.0, 0.7, 1.5, 5.0, 11.0]))
+    img = rng.integers(0, 65536, size=(2, y, x)).astype(np.uint16)
+    got = ops.to_numpy_u16(ops.gauss_blur(ops.to_device_u16(img, dev), (kx, ky), sig))
+    for k in range(2):
+        assert np.array_equal(got[k], O.gauss_blur(img[k], (kx, ky), sig)), ("blur", y, x, kx, ky, sig)
+    return f"blur {y}x{x} k=({kx},{ky}) sigma={sig}"
+
+
+def f_manual(rng, dev):
+    y, x = shape(rng, 8)
+    img = rng.integers(0, 65536, size=(3, y, x)).astype(np.uint16)
+    r0, r1 = sorted(int(v) for v in rng.integers(0, y, 2))
+    c0, c1 = sorted(int(v) for v in rng.integers(0, x, 2))
+    out, bg = ops.bg_manual(ops.to_device_u16(img, dev), (r0, c0, r1, c1))
+    for k in range(3):
+        eo, eb = O.bg_manual(img[k], r0, c0, r1, c1)
+        assert int(bg[k]) == eb and np.array_equal(ops.to_numpy_u16(out[k]), eo), ("manual", y, x, r0, c0, r1, c1)
+    return f"bg_manual {y}x{x} roi=({r0},{c0},{r1},{c1})"
+
+
+def f_measure(rng, dev):
+    y, x = shape(rng, 4, 200)
+    z = int(rng.choice([1, 1, 2, 5]))
+    c = int(rng.integers(1, 7))
+    t = int(rng.integers(1, 4))
+    kind = str(rng.choice(["discs", "random", "stripes", "huge_ids"]))
+    if kind == "discs":
+        lab = np.stack([np.stack([synth.make_labels(y, x, int(rng.integers(1, 30)), seed=int(rng.integers(1 << 30)))] * z)
+                        for _ in range(t)])
+    elif kind == "random":
+        lab = rng.integers(0, int(rng.integers(2, 3000)), size=(t, z, y, x)).astype(np.uint16)
+    elif kind == "stripes":
+        lab = np.broadcast_to((np.arange(x) // max(1, int(rng.integers(1, 9)))).astype(np.uint16), (t, z, y, x)).copy()
+    else:
+        lab = (rng.integers(0, 2, size=(t, z, y, x)) * rng.integers(60000, 65536, size=(t, z, y, x))).astype(np.uint16)
+    img = rng.integers(0, 65536, size=(t, c, z, y, x)).astype(np.uint16)
+    got = ops.measure_labels(ops.to_device_u16(img, dev), ops.to_device_u16(lab, dev))
+    for f in range(t):
+        e = O.measure_labels(img[f, :, 0], lab[f, 0]) if z == 1 else O.measure_labels(img[f], lab[f])
+        g = got[f]
+        for key in ("ids", "area", "sum", "centroid_rne"):
+            assert np.array_equal(g[key], e[key]), ("measure", key, kind, t, c, z, y, x)
+        assert np.array_equal(g["mean"].view(np.uint64), e["mean"].view(np.uint64)), ("measure mean", kind, t, c, z, y, x)
+    return f"measure {kind} {t}x{c}x{z}x{y}x{x}"
+
+
+def f_apply(rng, dev):
+    y, x = shape(rng, 4, 260)
+    img = rng.integers(0, 65536, size=(2, 1, y, x)).astype(np.uint16)
+    sh = []
+    for _ in range(2):
+        m = rng.random()
+        if m < 0.3:
+            sh.append((float(rng.integers(-y, y)), float(rng.integers(-x, x))))
+        elif m < 0.6:
+            sh.append((float(rng.integers(-9, 9)), float(rng.normal(0, 3))))
+        else:
+            sh.append((float(rng.normal(0, 4)), float(rng.normal(0, 4))))
+    got = ops.to_numpy_u16(ops.apply_shifts(ops.to_device_u16(img, dev), torch.tensor(sh, dtype=torch.float64, device=dev)))
+    for f in range(2):
+        exp = O.apply_shift(img[f, 0], sh[f][0], sh[f][1])
+        d = np.abs(got[f, 0].astype(np.int64) - exp.astype(np.int64)).max()
+        whole = float(sh[f][0]).is_integer() and float(sh[f][1]).is_integer()
+        assert d <= (0 if whole else 1), ("apply", y, x, sh[f], int(d))
+    return f"apply {y}x{x} {sh}"
+
+
+def f_edt(rng, dev):
+    y, x = shape(rng, 4, 160)
+    m = (rng.random((2, y, x)) < float(rng.choice([0.001, 0.02, 0.3, 0.9]))).astype(np.uint16)
+    if rng.random() < 0.2:
+        m[0] = 0
+    got = ops.edt_sq(ops.to_device_u16(m, dev)).cpu().numpy()
+    for k in range(2):
+        assert np.array_equal(got[k], O.edt_sq(m[k])), ("edt", y, x, k)
+    return f"edt {y}x{x}"
+
+
+def f_morph(rng, dev):
+    y, x = shape(rng, 8, 140)
+    lab = synth.make_labels(y, x, int(rng.integers(1, 12)), seed=int(rng.integers(1 << 30)))[None]
+    r = int(rng.integers(1, 12))
+    it = int(rng.integers(1, 3))
+    d = ops.to_device_u16(lab, dev)
+    assert np.array_equal(ops.to_numpy_u16(ops.label_erode(d, r, it))[0], O.label_erode(lab[0], r, it)), ("erode", y, x, r, it)
+    assert np.array_equal(ops.to_numpy_u16(ops.label_dilate(d, r, it))[0], O.label_dilate(lab[0], r, it)), ("dilate", y, x, r, it)
+    return f"morph {y}x{x} r={r} it={it}"
+
+
+def f_stitch(rng, dev):
+    y, x = shape(rng, 16, 120)
+    t = int(rng.integers(2, 6))
+    masks = np.stack([synth.make_labels(y, x, int(rng.integers(1, 10)), seed=int(rng.integers(1 << 30))) for _ in range(t)])
+    if rng.random() < 0.5:   # mostly persistent objects with a little jitter
+        base = synth.make_labels(y, x, int(rng.integers(2, 10)), seed=int(rng.integers(1 << 30)))
+        masks = np.stack([np.roll(base, (int(rng.integers(-2, 3)), int(rng.integers(-2, 3))), (0, 1)) for _ in range(t)])
+    thr = float(rng.choice([0.25, 0.5, 0.75]))
+    from imageanalysis_pipeline_amd.pipeline import Utility
+    got = Utility.modif_stitch3D(masks.copy(), thr)
+    exp = O.modif_stitch3D(masks.copy(), thr)
+    assert np.array_equal(got, exp), ("stitch", t, y, x, thr)
+    d = ops.to_device_u16(masks, dev)
+    assert np.array_equal(ops.to_numpy_u16(ops.label_mode(d)), O.label_mode(masks)), ("label_mode", t, y, x)
+    return f"stitch {t}x{y}x{x} thr={thr}"
+
+
+STAGES = [f_bg_smo, f_blur, f_manual, f_measure, f_apply, f_edt, f_morph, f_stitch]
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 80
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda:0")
+    for k in range(n):
+        fn = STAGES[k % len(STAGES)]
+        print(f"ok #{k} {fn(rng, dev)}", flush=True)
+    print("all", n, "cases agree")
+
+
+if __name__ == "__main__":
+    main()

@@ -120,3 +120,22 @@ def test_label_areas_are_bincounts(dev):
     a = ops.label_areas(ops.to_device_u16(m, dev)).cpu().numpy()
     for f in range(m.shape[0]):
         assert np.array_equal(a[f], np.bincount(m[f].ravel(), minlength=a.shape[1]))
+
+
+@pytest.mark.parametrize("shape", [(61, 23), (33, 35), (20, 42)])
+def test_odd_planes_take_the_scalar_paths(dev, shape):
+    """frames of a stack whose planes are not a multiple of 8 pixels start off a 16-byte boundary: label range,
+    overlap counting and relabelling read them one pixel at a time instead of refusing them (IAP_E_ALIGN until
+    scripts/fuzz_stages.py met such a stack through modif_stitch3D)"""
+    y, x = shape
+    t = 4
+    masks = np.stack([synth.make_labels(y, x, 6, seed=s) for s in range(t)])
+    d = ops.to_device_u16(masks, dev)
+    for f in range(t):
+        assert ops.max_label(d[f]) == int(masks[f].max())
+    ov = ops.label_overlap(d[1], d[2]).cpu().numpy()
+    assert np.array_equal(ov, O.label_overlap(masks[1], masks[2]))
+    lut = np.arange(int(masks.max()) + 1, dtype=np.uint16)[::-1].copy()
+    got = ops.to_numpy_u16(ops.relabel(d[3], ops.to_device_u16(lut, dev)))
+    assert np.array_equal(got, lut[masks[3]])
+    assert np.array_equal(Utility.modif_stitch3D(masks.copy(), 0.5), O.modif_stitch3D(masks.copy(), 0.5))
