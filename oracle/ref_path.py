@@ -671,6 +671,8 @@ def label_erode(mask: np.ndarray, r: int, iterations: int = 1) -> np.ndarray:
     for _ in range(iterations):
         keep = m != 0
         for dy, dx in disk_offsets(r):
+            if abs(dy) >= y or abs(dx) >= x:
+                continue                                   # the whole shifted plane lies outside the image
             sh = np.full_like(m, -1)                       # -1 = outside the image: matches everything
             ys, yd = slice(max(dy, 0), y + min(dy, 0)), slice(max(-dy, 0), y + min(-dy, 0))
             xs, xd = slice(max(dx, 0), x + min(dx, 0)), slice(max(-dx, 0), x + min(-dx, 0))
@@ -687,6 +689,8 @@ def label_dilate(mask: np.ndarray, r: int, iterations: int = 1) -> np.ndarray:
     for _ in range(iterations):
         out = m.copy()
         for dy, dx in disk_offsets(r):
+            if abs(dy) >= y or abs(dx) >= x:
+                continue
             ys, yd = slice(max(dy, 0), y + min(dy, 0)), slice(max(-dy, 0), y + min(-dy, 0))
             xs, xd = slice(max(dx, 0), x + min(dx, 0)), slice(max(-dx, 0), x + min(-dx, 0))
             out[yd, xd] = np.maximum(out[yd, xd], m[ys, xs])

@@ -145,7 +145,92 @@ def f_stitch(rng, dev):
     return f"stitch {t}x{y}x{x} thr={thr}"
 
 
-STAGES = [f_bg_smo, f_blur, f_manual, f_measure, f_apply, f_edt, f_morph, f_stitch]
+def f_smo_sigma(rng, dev):
+    y, x = shape(rng, 24, 200)
+    sig = float(rng.choice([0.5, 1.0, 2.0]))
+    size = int(rng.choice([5, 7]))
+    img = rng.integers(300, 900, size=(2, y, x)).astype(np.uint16)
+    got = ops.smo_image(ops.to_device_u16(img, dev), size=size, sigma=sig).cpu().numpy()
+    for k in range(2):
+        e = O.smo_image(img[k], sig, size)
+        assert np.abs(got[k] - e).max() < 3e-4, ("smo sigma", y, x, sig, size, float(np.abs(got[k] - e).max()))
+    got = ops.smo_image(ops.to_device_u16(img, dev), size=size).cpu().numpy()
+    for k in range(2):
+        assert np.abs(got[k] - O.smo_image(img[k], 0.0, size)).max() < 5e-6, ("smo", y, x, size)
+    return f"smo_image {y}x{x} sigma={sig} size={size}"
+
+
+def f_chan_shift(rng, dev):
+    y, x = shape(rng, 64, 200)
+    t, c, z = int(rng.integers(1, 3)), int(rng.integers(2, 4)), int(rng.choice([1, 1, 2]))
+    regc = int(rng.integers(0, c))
+    st, _ = synth.make_stack(t, c, z, y, x, n_cells=int(rng.integers(4, 10)), integer_drift=False,
+                             seed=int(rng.integers(1 << 30)))
+    # channels displaced against each other by a few pixels
+    for ch in range(c):
+        st[:, ch] = np.roll(st[:, ch], (int(rng.integers(-3, 4)), int(rng.integers(-3, 4))), (-2, -1))
+    out, sh = ops.chan_shift(ops.to_device_u16(st, dev), regc)
+    sh = sh.cpu().numpy()
+    eo, es = O.chan_shift_stack(st, regc)
+    assert np.abs(sh - es).max() < 0.01, ("chan_shift shifts", t, c, z, y, x, float(np.abs(sh - es).max()))
+    out = ops.to_numpy_u16(out)
+    for f in range(t):
+        for ch in range(c):
+            for zz in range(z):
+                exp = st[f, ch, zz] if ch == regc else O.apply_shift(st[f, ch, zz], sh[f, ch, zz, 0], sh[f, ch, zz, 1])
+                d = np.abs(out[f, ch, zz].astype(np.int64) - exp.astype(np.int64)).max()
+                assert d <= 1, ("chan_shift warp", t, c, z, y, x, int(d))
+    return f"chan_shift {t}x{c}x{z}x{y}x{x} reg={regc}"
+
+
+def f_tracks(rng, dev):
+    from imageanalysis_pipeline_amd.pipeline import Utility
+    y, x = shape(rng, 16, 100)
+    t = int(rng.integers(2, 7))
+    base = synth.make_labels(y, x, int(rng.integers(2, 12)), seed=int(rng.integers(1 << 30)))
+    masks = np.stack([base.copy() for _ in range(t)])
+    for f in range(t):        # objects vanish, shrink or get a stray id in some frames
+        for obj in np.unique(base)[1:]:
+            r = rng.random()
+            if r < 0.15:
+                masks[f][masks[f] == obj] = 0
+            elif r < 0.3:
+                sel = np.argwhere(masks[f] == obj)
+                masks[f][tuple(sel[: len(sel) // 2].T)] = 0
+    thr = float(rng.choice([0.1, 0.2, 0.5]))
+    got = Utility.filter_mask_shapes(masks.copy(), thr)
+    assert np.array_equal(got, O.filter_mask_shapes(masks.copy(), thr)), ("filter_mask_shapes", t, y, x, thr)
+    assert np.array_equal(Utility.renumber_masks(masks.copy()), O.renumber_masks(masks.copy())), ("renumber", t, y, x)
+    assert np.array_equal(Utility.trim_incomplete_tracks(masks.copy(), t), O.trim_incomplete_tracks(masks.copy(), t)), ("trim", t, y, x)
+    return f"tracks {t}x{y}x{x} thr={thr}"
+
+
+def f_pixel_table(rng, dev):
+    y, x = shape(rng, 8, 140)
+    t, c = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    img = rng.integers(0, 65536, size=(t, c, y, x)).astype(np.uint16)
+    cells = np.stack([synth.make_labels(y, x, int(rng.integers(1, 9)), seed=int(rng.integers(1 << 30))) for _ in range(t)])
+    ref = (rng.random((t, y, x)) < float(rng.choice([0.002, 0.05, 0.4]))).astype(np.uint16)
+    pix = float(rng.choice([0.5, 0.65, 1.0, 1.3]))
+    d_ref = ops.to_device_u16(ref, dev)
+    counts, dmap, vals = ops.masked_pixels(ops.to_device_u16(cells, dev), ops.to_device_u16(img, dev), ops.edt_sq(d_ref), pix)
+    counts, dmap, vals = counts.cpu().numpy(), dmap.cpu().numpy(), vals.cpu().numpy().view(np.uint16)
+    pos = 0
+    for f in range(t):
+        if not ref[f].any():
+            pos += int(counts[f])
+            continue            # no reference pixel: the distance is undefined (scipy/mahotas: see the dmap tests)
+        ed, ev = O.pixel_table(cells[f], img[f], ref[f], pix)
+        n = int(counts[f])
+        assert n == len(ed), ("pixel_table count", t, c, y, x)
+        assert np.array_equal(dmap[pos:pos + n], ed), ("pixel_table dmap", t, c, y, x, pix)
+        assert np.array_equal(vals[:, pos:pos + n].T, ev), ("pixel_table values", t, c, y, x)
+        pos += n
+    return f"pixel_table {t}x{c}x{y}x{x} pix={pix}"
+
+
+STAGES = [f_bg_smo, f_blur, f_manual, f_measure, f_apply, f_edt, f_morph, f_stitch, f_smo_sigma, f_chan_shift, f_tracks,
+          f_pixel_table]
 
 
 def main():
