@@ -1,6 +1,6 @@
 """Development aid (GPU): randomised differential run of the hot path against the oracle -- odd plane sizes, every
 reference mode, z-stacks, integer and sub-pixel drift, sparse and dense labels.
-    python scripts/fuzz_path.py [cases] [seed]
+    python scripts/fuzz_path.py [cases] [seed] [max_side]
 Per case: background levels exact; shifts within 0.01 px (exact for integer drift without refinement); the registered
 stack within 1 count of the oracle's warp at the GPU's shifts; tables bit-exact for the GPU's registered stack."""
 import os
@@ -14,11 +14,15 @@ from imageanalysis_pipeline_amd import ops, synth  # noqa: E402
 from oracle import ref_path as O  # noqa: E402
 
 
+MAX_SIDE = 420
+
+
 def one(rng, dev, k):
-    y = int(rng.integers(64, 420))
-    x = int(rng.integers(64, 420))
+    y = int(rng.integers(64, MAX_SIDE))
+    x = int(rng.integers(64, MAX_SIDE))
     if rng.random() < 0.3:
-        y, x = int(rng.choice([64, 128, 256, 512])), int(rng.choice([64, 128, 256, 512]))
+        p2 = [s for s in (64, 128, 256, 512, 1024, 2048) if s <= max(512, MAX_SIDE)]
+        y, x = int(rng.choice(p2)), int(rng.choice(p2))
     t = int(rng.integers(1, 6))
     c = int(rng.integers(1, 4))
     z = int(rng.choice([1, 1, 1, 2, 3]))
@@ -92,6 +96,8 @@ def one(rng, dev, k):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    global MAX_SIDE
+    MAX_SIDE = int(sys.argv[3]) if len(sys.argv) > 3 else 420
     rng = np.random.default_rng(seed)
     dev = torch.device("cuda:0")
     for k in range(n):

@@ -1,6 +1,7 @@
 """Development aid (GPU): randomised differential run of the single stages and the widening primitives against the
 oracle -- shapes, parameters and label statistics the fixed tests do not visit.
-    python scripts/fuzz_stages.py [cases] [seed]
+    python scripts/fuzz_stages.py [cases] [seed] [scale]
+scale > 1 stretches the upper shape bounds (multi-strip / multi-band / multi-tile launches of the same kernels).
 Bit-exact everywhere except the SMO image (2e-6, 3e-4 with sigma > 0)."""
 import os
 import sys
@@ -13,7 +14,11 @@ from imageanalysis_pipeline_amd import ops, synth  # noqa: E402
 from oracle import ref_path as O  # noqa: E402
 
 
+SCALE = 1
+
+
 def shape(rng, lo=16, hi=300):
+    hi = int(hi * SCALE)
     return int(rng.integers(lo, hi)), int(rng.integers(lo, hi))
 
 
@@ -236,6 +241,8 @@ STAGES = [f_bg_smo, f_blur, f_manual, f_measure, f_apply, f_edt, f_morph, f_stit
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 80
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    global SCALE
+    SCALE = float(sys.argv[3]) if len(sys.argv) > 3 else 1
     rng = np.random.default_rng(seed)
     dev = torch.device("cuda:0")
     for k in range(n):
