@@ -597,12 +597,16 @@ __global__ __launch_bounds__(256) void gauss_reflect_kernel(const T* __restrict_
   if (idx >= (long long)Y * X) return;
   int y = (int)(idx / X), x = (int)(idx - (long long)y * X);
   const T* p = in + (size_t)plane * Y * X;
+  // Integer planes are filtered relative to their first pixel (exact differences): only gradients of the result are
+  // used, a constant does not reach them, and the float32 rounding then scales with the plane's contrast instead of
+  // its level.
+  const float base = sizeof(T) == 2 ? (float)p[0] : 0.f;
   float acc = 0.f, wsum = 0.f;
   for (int k = -radius; k <= radius; ++k) {
     float w = __expf(-0.5f * (float)(k * k) / (sigma * sigma));
     int yy = axis == 0 ? reflect_idx(y + k, Y) : y;
     int xx = axis == 1 ? reflect_idx(x + k, X) : x;
-    acc += w * (float)p[(size_t)yy * X + xx];
+    acc += w * ((float)p[(size_t)yy * X + xx] - base);
     wsum += w;
   }
   out[(size_t)plane * Y * X + idx] = acc / wsum;
