@@ -1943,6 +1943,14 @@ extern "C" void iap_debug_col_stamps(unsigned long long* host16) {
 }
 #endif
 
+#ifdef IAP_AP_STAMPS
+extern "C" void iap_debug_ap_stamps(unsigned long long* host8) {
+  (void)hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_ap_stamps), 8 * sizeof(unsigned long long));
+  unsigned long long z[8] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ap_stamps), z, sizeof(z));
+}
+#endif
+
 extern "C" int iap_mip_u16(const uint16_t* in, int64_t in_stride, uint16_t* out, int64_t n, int Z, int Y, int X,
                            void* stream) {
   IAP_REQUIRE(in && out, IAP_E_ARG, "iap_mip_u16: null pointer");
