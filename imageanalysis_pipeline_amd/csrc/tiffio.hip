@@ -97,7 +97,7 @@ static Err parse_dir(int fd, const char* path, TiffDir& d) {
     const int typ = rd16(en + 2, be);
     const uint32_t cnt = rd32(en + 4, be);
     const int size = typ == 3 ? 2 : (typ == 4 ? 4 : (typ == 1 ? 1 : 0));
-    if (!size || cnt > (1u << 26)) return false;
+    if (!size || cnt == 0 || cnt > (1u << 24)) return false;   // (a strip per row of a 16M-row plane: nothing real comes near)
     std::vector<unsigned char> buf((size_t)size * cnt);
     if ((size_t)size * cnt <= 4) memcpy(buf.data(), en + 8, buf.size());
     else if (!pread_all(fd, buf.data(), buf.size(), rd32(en + 8, be))) return false;
@@ -237,7 +237,13 @@ static int run_pool(int64_t n, int threads, Fn fn) {
     for (;;) {
       const int64_t i = next.fetch_add(1);
       if (i >= n || stop.load()) return;
-      Err e = fn(i);
+      Err e;
+      try {
+        e = fn(i);
+      } catch (const std::exception& ex) {   // e.g. bad_alloc on a directory that claims a huge table: an error, not a terminate()
+        e.code = IAP_E_ARG;
+        e.msg = "plane " + std::to_string(i) + ": " + ex.what();
+      }
       if (e.code != IAP_OK) {
         std::lock_guard<std::mutex> lk(mu);
         if (first.code == IAP_OK) first = e;
@@ -265,7 +271,13 @@ extern "C" int iap_tiff_probe(const char* path, int* Y, int* X, int* bits, int* 
   int fd = open(path, O_RDONLY | O_CLOEXEC);
   IAP_REQUIRE(fd >= 0, IAP_E_ARG, "%s: %s", path, strerror(errno));
   TiffDir d;
-  Err e = parse_dir(fd, path, d);
+  Err e;
+  try {
+    e = parse_dir(fd, path, d);
+  } catch (const std::exception& ex) {
+    e.code = IAP_E_ARG;
+    e.msg = std::string(path) + ": " + ex.what();
+  }
   close(fd);
   if (e.code != IAP_OK) {
     set_error("%s", e.msg.c_str());
