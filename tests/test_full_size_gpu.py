@@ -50,6 +50,22 @@ def test_c2_sized_stack_high_offsets(dev):
             sums.index_add_(0, lab, (out[f, ch, 0].view(torch.int16).to(torch.int64) & 0xFFFF).view(-1).to(torch.float64))
             exp = sums[1:] / area[f, 1:].to(torch.float64)
             assert torch.equal(mean[f, 1:, ch], exp), (f, ch)
+    # --- reg_ref='mean' over all 500 frames: the reference rebuilt by torch (float64 mean of the lowered registration
+    # planes) and handed to the estimator gives the shifts of the far-end frames
+    del tables, small, small_out, tb2
+    tbm, shm, lvm = ops.hot_path(stack, labels, thr, reg_ref="mean", out=out)
+    assert torch.equal(lvm, levels)
+    med2 = lvm.view(t, c)[:, 0].to(torch.int64)
+    lowered = lambda f: ((2 * (stack[f, 0, 0].view(torch.int16).to(torch.int64) & 0xFFFF) - med2[f]).clamp_(min=0) >> 1)   # noqa: E731
+    acc = torch.zeros((y, x), dtype=torch.int64, device=dev)
+    for f in range(t):
+        acc += lowered(f)
+    ref = (acc.to(torch.float64) / t).to(torch.float32)
+    far = list(range(t - 4, t))
+    mov = torch.stack([lowered(f).to(torch.int16) for f in far]).view(torch.uint16)     # values < 32768 here
+    chk = ops.estimate_shifts(ref, mov)
+    assert float((chk - shm[far]).abs().max()) < 2e-3, (chk, shm[far])
+    assert torch.equal(tbm[0].sum(dim=1), torch.full((t,), y * x, dtype=tbm[0].dtype, device=dev))
     # every level is a background level of the synthetic planes (Poisson(100) + 400 -> 2 x ~500)
     lv = levels.cpu().numpy()
     assert lv.min() > 900 and lv.max() < 1100, (lv.min(), lv.max())
