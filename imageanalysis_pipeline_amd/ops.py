@@ -619,6 +619,24 @@ def relabel(masks: torch.Tensor, lut: torch.Tensor, out: torch.Tensor | None = N
     return out
 
 
+def _column_modes(cols: np.ndarray) -> np.ndarray:
+    """Most frequent non-zero value of every column of ``cols`` (T, K) u16, ties to the smaller value, 0 for a column
+    of zeros: all columns at once (sorted runs, their lengths, first longest run)."""
+    t, k = cols.shape
+    v = np.sort(cols, axis=0)
+    start = np.ones((t, k), dtype=bool)
+    start[1:] = v[1:] != v[:-1]
+    run = np.cumsum(start, axis=0) - 1                       # run number of every element within its column
+    col = np.broadcast_to(np.arange(k), (t, k))
+    length = np.zeros((t, k), dtype=np.int32)
+    np.add.at(length, (run, col), 1)
+    value = np.zeros((t, k), dtype=np.uint16)
+    value[run, col] = v
+    length[value == 0] = 0                                   # the background run does not compete
+    best = length.argmax(axis=0)                             # runs are in ascending value order: ties -> smaller label
+    return value[best, np.arange(k)]
+
+
 def label_mode(masks: torch.Tensor) -> torch.Tensor:
     """Master mask of utility.py:707-711: per pixel the most frequent non-zero label over the T leading
     planes of ``masks`` (ties: smaller label; 0 if never labelled)."""
@@ -634,13 +652,7 @@ def label_mode(masks: torch.Tensor) -> torch.Tensor:
         flat = out.view(-1).view(torch.int16)       # torch indexes int16, not uint16
         idx = torch.nonzero(flat == -1).squeeze(1)
         cols = masks.reshape(t, px).view(torch.int16)[:, idx].cpu().numpy().view(np.uint16)
-        fix = np.zeros(cols.shape[1], dtype=np.uint16)
-        for k in range(cols.shape[1]):
-            v = cols[:, k]
-            v = v[v != 0]
-            vals, cnt = np.unique(v, return_counts=True)
-            fix[k] = vals[np.argmax(cnt)] if len(vals) else 0
-        flat[idx] = torch.from_numpy(fix.view(np.int16)).to(masks.device)
+        flat[idx] = torch.from_numpy(_column_modes(cols).view(np.int16)).to(masks.device)
     return out
 
 
