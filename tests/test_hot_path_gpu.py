@@ -181,3 +181,40 @@ def test_side_streams_give_the_same_bits(dev):
         assert torch.equal(g[1], r[1]) and torch.equal(g[2], r[2])
         for a, b in zip(g[0], r[0]):
             assert torch.equal(a, b)
+
+
+def test_two_host_threads_give_the_same_bits(dev):
+    """two host threads, each with its own stream and FOV, inside the library at the same time (ctypes drops the GIL
+    for the call): the library's host state is thread-local or locked, scratch is per stream -- results equal the
+    sequential runs"""
+    import threading
+    t, c, y, x = 6, 2, 128, 192
+    fovs = []
+    for seed in (21, 22, 23, 24):
+        st, _ = synth.make_stack(t, c, 1, y, x, n_cells=9, integer_drift=False, seed=seed)
+        fovs.append((ops.to_device_u16(st, dev), ops.to_device_u16(_labels(t, 1, y, x, 6, seed=seed), dev)))
+    ref = [ops.hot_path(d, dl, THR, reg_ref="mean") for d, dl in fovs]
+    torch.cuda.synchronize()
+    got = [None] * len(fovs)
+    errs = []
+
+    def work(k):
+        try:
+            s = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(s):
+                for _ in range(5):        # several rounds, so that the calls of the threads interleave
+                    got[k] = ops.hot_path(fovs[k][0], fovs[k][1], THR, reg_ref="mean")
+            s.synchronize()
+        except Exception as e:            # noqa: BLE001
+            errs.append((k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(fovs))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errs, errs
+    for g, r in zip(got, ref):
+        assert torch.equal(g[1], r[1]) and torch.equal(g[2], r[2])
+        for a, b in zip(g[0], r[0]):
+            assert torch.equal(a, b)
