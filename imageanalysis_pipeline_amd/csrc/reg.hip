@@ -792,7 +792,7 @@ constexpr int UP_HALF = 7;
 constexpr float UP_STEP = 0.1f;
 constexpr int UP_UB_MIN = 16;  // fewest spectrum rows a workgroup takes (reached when few frames are in flight)
 constexpr int UP_YS = 16;      // floats per row record   {Ks(y'_0 - y) .. Ks(y'_14 - y), (-1)^y / Py}  (one 64-byte scalar load)
-constexpr int UP_XS = 20;      // floats per column record {w base.x, w base.y, 0, 0 | 1, a1..a7 | b1..b7, 0}
+constexpr int UP_XS = 20;      // floats per column record {w base.x, w base.y, 0, 0 | 1, a1-1..a7-1 | b1..b7, 0}
 constexpr int UP_NV = UP_N * UP_N;  // 225 grid values
 constexpr int UP_NQ = 32;      // floats per Nyquist-column partial: the 16 weighted row sums as complex pairs
 typedef cf v2f;
@@ -819,14 +819,24 @@ __device__ __forceinline__ void row_weight_consts(int j, int Py, double* k) {
   sincospi(f * (1.0 - 1.0 / (double)Py), &k[0], &k[1]);
   sincospi(f / (double)Py, &k[2], &k[3]);
 }
-__device__ __forceinline__ float row_weight(double sa, double ca, bool odd, const double* k, int Py) {
+__device__ __forceinline__ double row_weight(double sa, double ca, bool odd, const double* k, int Py) {
   const double den = sa * k[3] + ca * k[2];
-  if (den == 0.0) return (float)((double)(Py - 1) / (double)Py);   // t = 0 (mod Py)
+  if (den == 0.0) return (double)(Py - 1) / (double)Py;   // t = 0 (mod Py)
   const double num = k[0] * ca - k[1] * sa;
-  return (float)((odd ? -num : num) / ((double)Py * den));
+  return (odd ? -num : num) / ((double)Py * den);
 }
 
-// T[j] (j = 0..14) from the weighted row sums: acc[j] + exp(-i pi y'_j) acc[15], y'_j = sy + 0.1 (j - 7)
+// The grid is evaluated as DIFFERENCES from its centre.  The refinement only looks at how the 225 values differ from
+// one another (arg-max, then a parabola through three neighbours), and on a broad correlation peak neighbouring values
+// differ by 1e-5 .. 1e-6 of their size: summed as they are in float32 they carry about that much rounding, and the
+// vertex moved by up to 0.02 px against the float64 oracle (small windows, broad blobs).  So the row weights of grid
+// row j != 7 are K(y'_j - y) - K(y'_7 - y), the column factors of grid column 7 +- m are exp(i phi m) - 1, both
+// formed before rounding to float; the sums are then small numbers with full relative precision:
+//   U[7][7] = V77,  U[j][7] = Vj7 - V77,  U[7][k] = V7k - V77,  U[j][k] = (Vjk - Vj7) - (V7k - V77)
+// and the finish kernel works on D[j][k] = Vjk - V77 = U[j][7] + U[7][k] + U[j][k] in double (V77 itself is not needed).
+//
+// T'[j] (j = 0..14) from the weighted row sums: acc[j] + e_j acc[15], e_j = exp(-i pi y'_j) (- exp(-i pi y'_7) for
+// j != 7), y'_j = sy + 0.1 (j - 7)
 __device__ __forceinline__ v2f up_row_sum(int j, int sy, const v2f* acc) {
   // cos, sin of pi m / 10, m = 0..7
   constexpr float C[8] = {1.f, 0.95105651629515357f, 0.80901699437494742f, 0.58778525229247313f,
@@ -835,7 +845,8 @@ __device__ __forceinline__ v2f up_row_sum(int j, int sy, const v2f* acc) {
                           0.95105651629515357f, 1.f, 0.95105651629515357f, 0.80901699437494742f};
   const int m = j >= UP_HALF ? j - UP_HALF : UP_HALF - j;
   const float sg = (sy & 1) ? -1.f : 1.f;
-  const float pc = sg * C[m], ps = (j >= UP_HALF ? -sg : sg) * S[m];   // exp(-i pi y') = (-1)^sy (cos - i sin)(pi (j-7)/10)
+  // exp(-i pi y') = (-1)^sy (cos - i sin)(pi (j-7)/10); off the centre row minus its value there, (-1)^sy
+  const float pc = sg * (m ? C[m] - 1.f : 1.f), ps = (j >= UP_HALF ? -sg : sg) * S[m];
   const v2f n = acc[UP_N];
   return (v2f){acc[j].x + (n.x * pc - n.y * ps), acc[j].y + (n.x * ps + n.y * pc)};
 }
@@ -882,8 +893,10 @@ __global__ __launch_bounds__(256) void upsample_tables_kernel(int Py, int Px, in
     double sa, ca;
     sincospi((double)n / (double)Py, &sa, &ca);
     float wgt[UP_YS];
+    const double w7 = row_weight(sa, ca, n & 1, wk[UP_HALF], Py);
 #pragma unroll
-    for (int j = 0; j < UP_N; ++j) wgt[j] = row_weight(sa, ca, n & 1, wk[j], Py);
+    for (int j = 0; j < UP_N; ++j)
+      wgt[j] = j == UP_HALF ? (float)w7 : (float)(row_weight(sa, ca, n & 1, wk[j], Py) - w7);
     wgt[UP_N] = ((i & 1) ? -1.f : 1.f) / (float)Py;
     float4* o = reinterpret_cast<float4*>(yrec + ((size_t)frame * Py + i) * UP_YS);
 #pragma unroll
@@ -898,9 +911,10 @@ __global__ __launch_bounds__(256) void upsample_tables_kernel(int Py, int Px, in
     const cf bs = unit_phase(fv, cs.y, Px, 0.f);
     o[0] = w * bs.x; o[1] = w * bs.y; o[2] = 0.f; o[3] = 0.f; o[4] = 1.f; o[UP_XS - 1] = 0.f;
 #pragma unroll
-    for (int m = 1; m <= UP_HALF; ++m) {
-      const cf e = unit_phase(fv, 0, Px, (float)m * UP_STEP);
-      o[4 + m] = e.x; o[11 + m] = e.y;
+    for (int m = 1; m <= UP_HALF; ++m) {   // exp(i phi) - 1 = -2 sin^2(phi/2) + i sin(phi), from the half angle
+      float sh, ch;
+      sincospif((float)fv * ((float)m * UP_STEP) / (float)Px, &sh, &ch);
+      o[4 + m] = -2.f * sh * sh; o[11 + m] = 2.f * sh * ch;
     }
   }
   if ((int)blockIdx.x < nyb) {  // uniform: this workgroup holds rows
@@ -1077,7 +1091,8 @@ __global__ __launch_bounds__(256) void upsample_finish_kernel(const float* __res
                                                               const float* __restrict__ xrec, int Wp, int Px,
                                                               const int2* __restrict__ coarse,
                                                               double* __restrict__ shifts) {
-  __shared__ float V[UP_N * UP_N];
+  __shared__ float U[UP_N * UP_N];
+  __shared__ double V[UP_N * UP_N];   // the grid minus its centre value (see up_row_sum)
   __shared__ float nq[UP_NQ];
   const int frame = blockIdx.x, tid = threadIdx.x;
   if (tid < UP_NQ) {
@@ -1108,12 +1123,21 @@ __global__ __launch_bounds__(256) void upsample_finish_kernel(const float* __res
       const float pv = cx * xr[4 + m], qv = m ? cy * xr[11 + m] : 0.f;
       s += k > UP_HALF ? pv - qv : pv + qv;
     }
-    V[tid] = s;
+    U[tid] = s;
+  }
+  __syncthreads();
+  if (tid < UP_N * UP_N) {
+    const int j = tid / UP_N, k = tid - j * UP_N;
+    double d = 0.0;
+    if (j != UP_HALF) d += (double)U[j * UP_N + UP_HALF];
+    if (k != UP_HALF) d += (double)U[UP_HALF * UP_N + k];
+    if (j != UP_HALF && k != UP_HALF) d += (double)U[tid];
+    V[tid] = d;
   }
   __syncthreads();
   __shared__ float shv[16];
   __shared__ int shi[16];
-  float bv = tid < UP_N * UP_N ? V[tid] : -INFINITY;
+  float bv = tid < UP_N * UP_N ? (float)V[tid] : -INFINITY;
   int best = tid < UP_N * UP_N ? tid : 0x7fffffff;
   block_argmax(bv, best, shv, shi);   // first maximum in row-major order, as np.argmax
   if (tid == 0) {
@@ -1123,9 +1147,9 @@ __global__ __launch_bounds__(256) void upsample_finish_kernel(const float* __res
     double cy = (double)cs.x + (double)(iy - UP_HALF) * 0.1;
     double cx = (double)cs.y + (double)(ix - UP_HALF) * 0.1;
     if (iy > 0 && iy < UP_N - 1)
-      cy += 0.1 * parabola((double)V[(iy - 1) * UP_N + ix], (double)V[best], (double)V[(iy + 1) * UP_N + ix]);
+      cy += 0.1 * parabola(V[(iy - 1) * UP_N + ix], V[best], V[(iy + 1) * UP_N + ix]);
     if (ix > 0 && ix < UP_N - 1)
-      cx += 0.1 * parabola((double)V[iy * UP_N + ix - 1], (double)V[best], (double)V[iy * UP_N + ix + 1]);
+      cx += 0.1 * parabola(V[iy * UP_N + ix - 1], V[best], V[iy * UP_N + ix + 1]);
     shifts[2 * frame] = cy;
     shifts[2 * frame + 1] = cx;
   }

@@ -31,7 +31,7 @@ def one(rng, dev, k):
     up = not integer or bool(rng.random() < 0.3)
     regc = int(rng.integers(0, c))
     ncell = int(rng.integers(3, 14))
-    st, _ = synth.make_stack(t, c, z, y, x, n_cells=ncell, integer_drift=integer, seed=int(rng.integers(1 << 30)))
+    st, drift = synth.make_stack(t, c, z, y, x, n_cells=ncell, integer_drift=integer, seed=int(rng.integers(1 << 30)))
     lab2 = synth.make_labels(y, x, int(rng.integers(1, 40)), seed=int(rng.integers(1 << 30)))
     lab = np.broadcast_to(lab2[None, None], (t, z, y, x)).copy()
     if rng.random() < 0.2:
@@ -73,7 +73,13 @@ def one(rng, dev, k):
             es = sh.copy()
             err = 0.0
     else:
-        assert err < 0.01, (desc, "shifts", sh, es)
+        # Where the oracle itself has lost the frame (no cell inside the estimate's centre window: its "shift" is the
+        # highest bump of a noise surface, far from the drift that was applied) the vertex of that bump is not a
+        # quantity with two stable decimals: the same bump must be found, to 0.05 px.
+        lost = mode == "first" and bool((np.abs(es + (drift - drift[0])) > 1.5).any())
+        assert err < (0.05 if lost else 0.01), (desc, "shifts", sh, es)
+        if lost:
+            print(f"   (the oracle's shifts are {np.abs(es + (drift - drift[0])).max():.0f} px from the applied drift: registration lost on both sides, same peak)")
     worst = 0
     for f in range(t):
         for ch in range(c):
