@@ -176,12 +176,12 @@ __device__ __forceinline__ void fft_publish() {
 }
 
 // One Stockham radix-R pass over an N-point sequence held in LDS (padded index), done by
-// N/E threads (E points each).  tw[k] = exp(-2 pi i k / N).  Ends with a barrier (fft_sync).
+// N/E threads (E points each).  tw[k] = exp(-2 pi i k / N).  The read half leaves the twiddled, transformed
+// values in registers; the write half puts them back (autosort order) and ends with a barrier (fft_sync).
 template <int N, int E, int R, int SIGN, int Ns>
-__device__ __forceinline__ void fft_pass(cf* s, int j, const cf* __restrict__ tw) {
+__device__ __forceinline__ void fft_pass_read(const cf* s, int j, const cf* __restrict__ tw, cf (&v)[E / R][R]) {
   constexpr int NT = N / E;
   constexpr int NB = E / R;
-  cf v[NB][R];
   cf w1[NB];
   // every read of the pass is issued before anything waits for one: left alone, the scheduler threads the reads
   // one by one into the twiddle chain and each then costs a full LDS round trip
@@ -216,7 +216,12 @@ __device__ __forceinline__ void fft_pass(cf* s, int j, const cf* __restrict__ tw
     }
     dftR<R, SIGN>(v[b]);
   }
-  fft_sync<NT>();
+}
+
+template <int N, int E, int R, int Ns>
+__device__ __forceinline__ void fft_pass_write(cf* s, int j, const cf (&v)[E / R][R]) {
+  constexpr int NT = N / E;
+  constexpr int NB = E / R;
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int jj = j + b * NT;
@@ -230,15 +235,28 @@ __device__ __forceinline__ void fft_pass(cf* s, int j, const cf* __restrict__ tw
       for (int r = 0; r < R; ++r) s[padi<E>(base + r * Ns)] = v[b][r];
     }
   }
-  fft_sync<NT>();
+  fft_sync<N / E>();
+}
+
+template <int N, int E, int R, int SIGN, int Ns>
+__device__ __forceinline__ void fft_pass(cf* s, int j, const cf* __restrict__ tw) {
+  cf v[E / R][R];
+  fft_pass_read<N, E, R, SIGN, Ns>(s, j, tw, v);
+  fft_sync<N / E>();
+  fft_pass_write<N, E, R, Ns>(s, j, v);
+}
+
+// 16-point passes where a thread holds 16 points (a pass less through LDS for N >= 256), else 8
+template <int N, int E, int Ns>
+constexpr int pass_radix() {
+  constexpr int rem = N / Ns;
+  return (E >= 16 && rem >= 16) ? 16 : (rem >= 8 ? 8 : rem);
 }
 
 template <int N, int E, int SIGN, int Ns>
 __device__ __forceinline__ void fft_rec(cf* s, int j, const cf* __restrict__ tw) {
   if constexpr (Ns < N) {
-    constexpr int rem = N / Ns;
-    // 16-point passes where a thread holds 16 points (a pass less through LDS for N >= 256), else 8
-    constexpr int R = (E >= 16 && rem >= 16) ? 16 : (rem >= 8 ? 8 : rem);
+    constexpr int R = pass_radix<N, E, Ns>();
     fft_pass<N, E, R, SIGN, Ns>(s, j, tw);
     fft_rec<N, E, SIGN, Ns * R>(s, j, tw);
   }
@@ -251,22 +269,79 @@ __device__ __forceinline__ void fft_lds(cf* s, int j, const cf* __restrict__ tw)
   fft_rec<N, E, SIGN, 1>(s, j, tw);
 }
 
+// Forward FFT whose LAST pass stays in registers: x[m] = X[j + m N/E], m < E.  That is exactly the set the first
+// pass of an E-radix transform of the same length reads (its thread j takes the elements j + r N/E), so a
+// pointwise product followed by the inverse transform needs no LDS round trip in between: the last forward
+// pass's stores, the product's loads and stores and the first inverse pass's loads -- a quarter of the column
+// kernel's LDS traffic at 2048 points -- and three of its barriers go.
+template <int N, int E, int Ns>
+__device__ __forceinline__ void fft_fwd_open_rec(cf* s, int j, const cf* __restrict__ tw, cf (&x)[E]) {
+  constexpr int R = pass_radix<N, E, Ns>();
+  if constexpr (Ns * R == N) {
+    constexpr int NB = E / R;
+    cf v[NB][R];
+    fft_pass_read<N, E, R, -1, Ns>(s, j, tw, v);
+    // thread j, batch b, output r is element (j + b N/E) + r Ns = j + (b + NB r) N/E
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < R; ++r) x[b + NB * r] = v[b][r];
+  } else {
+    fft_pass<N, E, R, -1, Ns>(s, j, tw);
+    fft_fwd_open_rec<N, E, Ns * R>(s, j, tw, x);
+  }
+}
+template <int N, int E>
+__device__ __forceinline__ void fft_fwd_open(cf* s, int j, const cf* __restrict__ tw, cf (&x)[E]) {
+  static_assert(pass_radix<N, E, 1>() < N, "at least two passes");
+  fft_fwd_open_rec<N, E, 1>(s, j, tw, x);
+}
+// Inverse FFT whose first pass takes its input from registers (x[m] = element j + m N/E); the result is in LDS.
+// Every thread of the FFT must be past its last LDS read of the forward transform before the first store:
+// the barrier between the two halves of the pass does that, as in any other pass.
+template <int N, int E>
+__device__ __forceinline__ void fft_inv_regs(cf* s, int j, const cf* __restrict__ tw, cf (&x)[E]) {
+  constexpr int R = pass_radix<N, E, 1>();
+  static_assert(R == E, "the first pass is one E-point transform per thread");
+  cf v[1][R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) v[0][r] = x[r];
+  dftR<R, +1>(v[0]);
+  fft_sync<N / E>();
+  fft_pass_write<N, E, R, 1>(s, j, v);
+  fft_rec<N, E, +1, R>(s, j, tw);
+}
+
 template <int N>
 struct FftGeom {
   static constexpr int NT = N / 8;                            // threads per FFT
   static constexpr int PADN = N + N / 8;                      // padded LDS points per FFT
   static constexpr int G = (256 / NT) > 1 ? (256 / NT) : 1;   // row FFTs per workgroup
   static constexpr int TC = (8192 / N) < 16 ? (8192 / N) : 16;  // columns per workgroup
-#ifndef IAP_COL_E2048
-#define IAP_COL_E2048 16
-#endif
-  // points per thread in the column kernel; 32 at N = 2048 makes a column one wave's own (no barriers inside its FFT)
-  static constexpr int CE = N == 2048 ? IAP_COL_E2048 : (N >= 128 ? 16 : 8);
+  static constexpr int CE = N >= 128 ? 16 : 8;                // points per thread in the column kernels
   static constexpr int CNT = N / CE;                          // threads per column FFT
-  static constexpr int CWPS = CE >= 32 ? 2 : 4;               // waves per SIMD the column kernels are compiled for (LDS allows no more)
+  static constexpr int CWPS = 4;                              // waves per SIMD the column kernels are compiled for (LDS allows no more)
   static constexpr int TWL = (N / 2) < 256 ? (N / 2) : 256;   // twiddles the column passes index (k N / (Ns R) < N / R of the last pass)
-  static constexpr int CS = PADN + 8;                         // LDS stride between columns: the column pairs a lane pair touches sit 16 bank pairs apart
+  // LDS stride between columns: the padded column (N + N/16 for 16 points per thread) rounded up to 1 mod 16, so
+  // that the 16 lanes that stage 4-row pieces of 4 columns x 2 half blocks x 2 blocks hit 16 different bank pairs
+  static constexpr int CS = ((CE >= 16 ? N + N / 16 : PADN) + 15) / 16 * 16 + 1;
+  // Row pairs per workgroup of the row kernels that write / read the row-interleaved spectra (below): 8 rows
+  // (a whole 128-byte line per 4-column tile of F) where 1024 threads allow it, at least 4 rows (Q's interleave).
+  static constexpr int RP16 = NT >= 512 ? 2 : (G >= 4 ? G : 4);
+  static constexpr int RPQ = G >= 2 ? G : 2;
 };
+
+// Spectra in HBM.  The moving planes' row spectra F (half pairs) and the column pass's output Q (float pairs) are
+// ROW-INTERLEAVED: the same column of 8 (F) or 4 (Q) consecutive rows is contiguous,
+//   F[((y / 8) * Wp + v) * 8 + y % 8],   Q[((y / 4) * Wp + v) * 4 + y % 4],
+// so that a tile of 4 columns x 8 (4) rows is one 128-byte line.  The column kernel owns whole columns: with
+// row-major spectra every line of F was fetched by 8 workgroups and every line of Q written by 4, 16 and 32 bytes at
+// a time, and the kernel ran at the rate of those requests, not of its FFTs (measured with the addresses faked
+// contiguous: 798 -> 539 us per 64 frames of 2048^2).  The row kernels take 8 (4) rows per workgroup and stream whole
+// blocks; the refinement reads 4 rows of a column as 32 contiguous bytes.  The reference plane's float row spectrum
+// (one per call) stays row-major.
+__device__ __forceinline__ size_t f_at(int y, int v, int Wp) { return ((size_t)(y >> 3) * Wp + v) * 8 + (y & 7); }
+__device__ __forceinline__ size_t q_at(int y, int v, int Wp) { return ((size_t)(y >> 2) * Wp + v) * 4 + (y & 3); }
 
 __global__ void twiddle_kernel(cf* tw, int n) {
   int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -308,15 +383,16 @@ __device__ __forceinline__ cf from_h2(h2 v) { return __builtin_convertvector(v, 
 template <int N> constexpr float fs16() { return 0.5f / (float)N; }
 
 template <int N, bool OUT16>
-__global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_r2c_kernel(
+__global__ __launch_bounds__((OUT16 ? FftGeom<N>::RP16 : FftGeom<N>::G) * FftGeom<N>::NT) void rows_r2c_kernel(
     const void* __restrict__ src, int kind, long long plane_stride, int srcX, int oy, int ox, float in_scale,
     void* __restrict__ Fv, long long F_stride, int Wp, const cf* __restrict__ tw, int vec,
     const int* __restrict__ sub2, long long sub_stride) {
   using Gm = FftGeom<N>;
+  constexpr int RP = OUT16 ? Gm::RP16 : Gm::G;   // row pairs per workgroup
   extern __shared__ cf lds_c[];
   const int g = threadIdx.x / Gm::NT, j = threadIdx.x % Gm::NT;
   cf* s = lds_c + g * Gm::PADN;
-  const int pair = blockIdx.x * Gm::G + g;
+  const int pair = blockIdx.x * RP + g;
   const int ra = 2 * pair;
   const int lv = kind == 0 ? plane_level(sub2, (long long)blockIdx.y * sub_stride) : 0;   // u16 sources only
   const size_t base = (size_t)blockIdx.y * plane_stride;
@@ -344,43 +420,65 @@ __global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_r2c_kernel
   }
   __syncthreads();
   fft_lds<N, -1>(s, j, tw);
-  if (OUT16) {
-    h2* Fa = reinterpret_cast<h2*>(Fv) + (size_t)blockIdx.y * F_stride + (size_t)ra * Wp;
-    h2* Fb = Fa + Wp;
-    for (int k = j; k <= N / 2; k += Gm::NT) {
-      cf zk = s[padi<8>(k)];
-      cf zn = s[padi<8>((N - k) & (N - 1))];
-      Fa[k] = to_h2(mkc(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y)));
-      Fb[k] = to_h2(mkc(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x)));
-    }
+  // two real rows per complex transform: Fa[k] = (Z[k] + conj Z[N-k]) / 2, Fb[k] = (Z[k] - conj Z[N-k]) / 2i
+  auto split = [&](const cf* sp, int k, cf& fa, cf& fb) {
+    const cf zk = sp[padi<8>(k)], zn = sp[padi<8>((N - k) & (N - 1))];
+    fa = mkc(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+    fb = mkc(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+  };
+  if constexpr (OUT16) {
+    // 4 rows (two pairs) of one column per 16-byte store; 32 consecutive lanes take consecutive columns of one
+    // row quad (conflict-free LDS reads), the lanes 32 apart the other quad of the same 8-row block: a wave's
+    // store is one contiguous run of whole lines
+    static_assert(RP % 2 == 0, "whole row quads");
+    fft_publish<Gm::NT>();   // the quads are read across the transforms' own thread groups
+    constexpr int NQ = RP / 2, NTH = RP * Gm::NT, LG = NTH / NQ < 32 ? NTH / NQ : 32, KSTEP = LG * (NTH / (LG * NQ));
+    static_assert(NTH % (LG * NQ) == 0, "whole lane groups per quad");
+    const int t = threadIdx.x;
+    const int q = (t / LG) % NQ;
+    const int y0 = (int)blockIdx.x * 2 * RP + 4 * q;
+    h2* Fo = reinterpret_cast<h2*>(Fv) + (size_t)blockIdx.y * F_stride;
+    const cf* sa = lds_c + (2 * q) * Gm::PADN;
+    const cf* sb = sa + Gm::PADN;
+    auto emit = [&](int k) {
+      cf f0, f1, f2, f3;
+      split(sa, k, f0, f1);
+      split(sb, k, f2, f3);
+      const h2 h0 = to_h2(f0), h1 = to_h2(f1), h2_ = to_h2(f2), h3 = to_h2(f3);
+      h8 o = {h0.x, h0.y, h1.x, h1.y, h2_.x, h2_.y, h3.x, h3.y};
+      *reinterpret_cast<h8*>(Fo + f_at(y0, k, Wp)) = o;
+    };
+    const int k0 = (t % LG) + LG * (t / (LG * NQ));   // < KSTEP = 2 NT = N / 4
+    static_assert(KSTEP * 2 == N / 2, "two rounds cover the bins below Nyquist");
+    emit(k0);
+    emit(k0 + KSTEP);
+    if (k0 == 0) emit(N / 2);
   } else {
     cf* Fa = reinterpret_cast<cf*>(Fv) + (size_t)blockIdx.y * F_stride + (size_t)ra * Wp;
     cf* Fb = Fa + Wp;
     for (int k = j; k <= N / 2; k += Gm::NT) {
-      cf zk = s[padi<8>(k)];
-      cf zn = s[padi<8>((N - k) & (N - 1))];
-      Fa[k] = mkc(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-      Fb[k] = mkc(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+      cf fa, fb;
+      split(s, k, fa, fb);
+      Fa[k] = fa;
+      Fb[k] = fb;
     }
   }
 }
 
 // K2 ---------------------------------------------------------------------------------------
 // Column pass on tiles of TC columns (XCD-remapped so that neighbouring tiles, which share cache lines of the
-// row-major spectra, run on one L2).  Half-precision tiles move in chunks of VW = min(TC, 4) complex values
-// (16 bytes for TC >= 4): a thread owns the chunks idx = tid + m * NTH, m < NL; chunk idx covers row
-// u = idx / CPR, columns (idx % CPR) * VW .. + VW - 1 of the tile (CPR = TC / VW chunks per row).
-//   cols_ref_kernel     the reference: float row spectrum -> column FFT -> G as half pairs in TILE-MAJOR chunk
-//                       order (what the threads of the cross-power kernel read: contiguous 16 bytes per lane),
-//                       scaled per tile by a power of two so that any float reference fits (gscale[tile] = the
-//                       factor that undoes it).
+// spectra, run on one L2).  Tiles of F and Q move as whole 128-byte lines of the row-interleaved layouts.
+// Thread tid = c * CNT + j works on column c of the tile; the last forward pass leaves it the spectrum values
+// u = j + m * CNT, m < CE, in registers (fft_fwd_open), where they meet the reference's and go straight into the
+// inverse transform.
+//   cols_ref_kernel     the reference: float row spectrum -> column FFT -> G as half pairs in the order the threads
+//                       of the cross-power kernel use them: chunk q (16 bytes = elements m = 4 q .. 4 q + 3) of
+//                       thread tid at (q * NTH + tid) * 4, so that a wave's load is one contiguous KiB; scaled per
+//                       tile by a power of two so that any float reference fits (gscale[tile] = the factor that
+//                       undoes it).
 //   cols_xpower_kernel  the moving frames, one (tile, frame) per workgroup: half tile -> LDS, column FFT,
 //                       P = G conj(F) (DC zeroed, optional / |P|; G one for all frames or one per frame: channel
 //                       shift pairs), inverse FFT, Q[y][v] stored as float (spatial along y, spectral along x).
-//                       (Measured and dropped: a workgroup walking several frames with the next tile's 16
-//                       registers in flight under the FFTs -- the 16-point passes already fill the 128 registers
-//                       of 4 waves/SIMD, 19 spill: 15.1 instead of 13.1 us/frame; the kernel is bound by LDS and
-//                       barrier latency at 4 waves per SIMD, not by its streams: halving them changed nothing.)
 //   cols_fused_kernel   the serial 'previous' chain: the reference arrives as its ROW spectrum (half pairs, F's
 //                       layout) and gets its column FFT in a second LDS tile of the same workgroup.
 template <int N>
@@ -388,67 +486,53 @@ struct ColGeom {
   using Gm = FftGeom<N>;
   static constexpr int TC = Gm::TC, CE = Gm::CE, CNT = Gm::CNT, CS = Gm::CS;
   static constexpr int NTH = TC * CNT;
-  static constexpr int VW = TC < 4 ? TC : 4;     // complex values per half-precision chunk
-  static constexpr int CPR = TC / VW;            // chunks per tile row
-  static constexpr int NL = CE / VW;             // chunks per thread
-  static_assert(TC % VW == 0 && CE % VW == 0 && (TC * N) % (NTH * VW) == 0, "whole chunks per thread");
-  static_assert(TC % 2 == 0 && CE % 2 == 0, "column pairs for the float stores");
+  static constexpr int NLG = CE / 4;             // 16-byte chunks of G per thread
+  static constexpr int NL4 = CE / 4;             // 16-byte chunks (4 rows of a column) of F per thread
+  static_assert(CE % 4 == 0 && N % 8 == 0, "whole chunks per thread, whole row blocks");
 };
 // the column kernels keep the twiddles their passes use in LDS: a pass then waits for an LDS read, not for L2
 template <int N>
 __device__ __forceinline__ void stage_twiddles(cf* tw_s, const cf* __restrict__ tw, int tid) {
   for (int i = tid; i < FftGeom<N>::TWL; i += ColGeom<N>::NTH) tw_s[i] = tw[i];
 }
-template <int VW> struct HChunk;
-template <> struct HChunk<4> { typedef h8 T; };
-template <> struct HChunk<2> { typedef h4 T; };
-
-// half tile (row-major spectrum F, Wp values per row) -> registers; columns past `nvalid` read as zero
+// Half tile of the row-interleaved spectrum F -> registers: 16-byte chunks of 4 rows of one column.  The tile's
+// share of an 8-row block is TC * 2 contiguous chunks (column c, rows 0..3 or 4..7 of the block): a thread owns the
+// chunks idx = tid + m * NTH, m < NL4, of the tile in that order, a wave's load is a run of whole lines.
 template <int N>
-__device__ __forceinline__ void load_half_tile(const h2* __restrict__ Ff, int Wp, int v0, int tid,
-                                               typename HChunk<ColGeom<N>::VW>::T (&w)[ColGeom<N>::NL]) {
+__device__ __forceinline__ void load_half_tile(const h2* __restrict__ Ff, int Wp, int v0, int tid, h8 (&w)[ColGeom<N>::NL4]) {
   using Cg = ColGeom<N>;
-  typedef typename HChunk<Cg::VW>::T HC;
 #pragma unroll
-  for (int m = 0; m < Cg::NL; ++m) {
+  for (int m = 0; m < Cg::NL4; ++m) {
     const int idx = tid + m * Cg::NTH;
-#ifdef IAP_COL_X_NOLOADF
-    w[m] = *reinterpret_cast<const HC*>(Ff + (size_t)(idx % 64) * Cg::VW);
-#else
-    w[m] = *reinterpret_cast<const HC*>(Ff + (size_t)(idx / Cg::CPR) * Wp + v0 + (idx % Cg::CPR) * Cg::VW);
-#endif
+    w[m] = *reinterpret_cast<const h8*>(Ff + ((size_t)(idx / (2 * Cg::TC)) * Wp + v0) * 8 + (idx % (2 * Cg::TC)) * 4);
   }
 }
 template <int N>
-__device__ __forceinline__ void stage_half_tile(cf* lds, int v0, int nvalid, int tid,
-                                                const typename HChunk<ColGeom<N>::VW>::T (&w)[ColGeom<N>::NL]) {
+__device__ __forceinline__ void stage_half_tile(cf* lds, int v0, int nvalid, int tid, const h8 (&w)[ColGeom<N>::NL4]) {
   using Cg = ColGeom<N>;
 #pragma unroll
-  for (int m = 0; m < Cg::NL; ++m) {
+  for (int m = 0; m < Cg::NL4; ++m) {
     const int idx = tid + m * Cg::NTH;
-    const int u = idx / Cg::CPR, c0 = (idx % Cg::CPR) * Cg::VW;
+    const int wi = idx % (2 * Cg::TC), c = wi >> 1, u0 = (idx / (2 * Cg::TC)) * 8 + (wi & 1) * 4;
+    const bool ok = v0 + c < nvalid;   // padding columns hold whatever the workspace held
+    cf* d = lds + c * Cg::CS;
 #pragma unroll
-    for (int h = 0; h < Cg::VW; ++h) {
-      cf v = from_h2((h2){w[m][2 * h], w[m][2 * h + 1]});
-      if (v0 + c0 + h >= nvalid) v = mkc(0.f, 0.f);   // padding columns hold whatever the workspace held
-      lds[(c0 + h) * Cg::CS + padi<Cg::CE>(u)] = v;
-    }
+    for (int h = 0; h < 4; ++h)   // (16 points per thread: 4 | u0, the four rows share a pad group and are contiguous)
+      d[padi<Cg::CE>(u0 + h)] = ok ? from_h2((h2){w[m][2 * h], w[m][2 * h + 1]}) : mkc(0.f, 0.f);
   }
 }
-// Q tile (LDS) -> float row-major spectrum, two neighbouring columns per 16-byte store
+// Q tile (LDS) -> row-interleaved float spectrum: two rows of one column per 16-byte store, the tile's share of a
+// 4-row block is TC * 2 contiguous chunks
 template <int N>
 __device__ __forceinline__ void store_float_tile(const cf* lds, cf* __restrict__ Qf, int Wp, int v0, int tid) {
   using Cg = ColGeom<N>;
-  constexpr int HP = Cg::TC / 2;
 #pragma unroll 4
   for (int m = 0; m < Cg::CE / 2; ++m) {
     const int idx = tid + m * Cg::NTH;
-    const int pc = idx % HP, u = idx / HP;
-    const cf a = lds[(2 * pc) * Cg::CS + padi<Cg::CE>(u)], b2 = lds[(2 * pc + 1) * Cg::CS + padi<Cg::CE>(u)];
-#ifdef IAP_COL_X_NOSTORE
-    if (a.x == 1.2345e-30f)
-#endif
-    *reinterpret_cast<float4*>(Qf + (size_t)u * Wp + v0 + 2 * pc) = make_float4(a.x, a.y, b2.x, b2.y);
+    const int wi = idx % (2 * Cg::TC), c = wi >> 1, u = (idx / (2 * Cg::TC)) * 4 + (wi & 1) * 2;
+    const cf* sp = lds + c * Cg::CS;
+    const cf a = sp[padi<Cg::CE>(u)], b2 = sp[padi<Cg::CE>(u + 1)];
+    *reinterpret_cast<float4*>(Qf + ((size_t)(idx / (2 * Cg::TC)) * Wp + v0) * 4 + wi * 2) = make_float4(a.x, a.y, b2.x, b2.y);
   }
 }
 __device__ __forceinline__ cf xpower(cf g, cf f, float scale, int normalize) {
@@ -461,13 +545,25 @@ __device__ __forceinline__ cf xpower(cf g, cf f, float scale, int normalize) {
   }
   return p;
 }
+// One column of the tile, already staged in LDS: forward FFT, times the reference (ref(m) = its value at
+// u = j + m * CNT), DC zeroed, inverse FFT back into the same LDS column.
+template <int N, typename REF>
+__device__ __forceinline__ void column_correlate(cf* s, int j, const cf* __restrict__ tw_s, REF ref, float sc,
+                                                 int normalize, bool dc_column) {
+  using Cg = ColGeom<N>;
+  cf x[Cg::CE];
+  fft_fwd_open<N, Cg::CE>(s, j, tw_s, x);
+#pragma unroll
+  for (int m = 0; m < Cg::CE; ++m) x[m] = xpower(x[m], ref(m), sc, normalize);
+  if (dc_column && j == 0) x[0] = mkc(0.f, 0.f);
+  fft_inv_regs<N, Cg::CE>(s, j, tw_s, x);
+}
 
 template <int N>
 __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, FftGeom<N>::CWPS) void cols_ref_kernel(
     const cf* __restrict__ F, long long F_stride, h2* __restrict__ G, long long G_stride, float* __restrict__ gscale,
     int gs_stride, int Wp, int nvalid, const cf* __restrict__ tw) {
   using Cg = ColGeom<N>;
-  typedef typename HChunk<Cg::VW>::T HC;
   extern __shared__ cf lds_c[];
   __shared__ float wmax[16];
   __shared__ cf tw_s[FftGeom<N>::TWL];
@@ -495,27 +591,18 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, FftGeom<N>::CWPS) 
     }
   }
   __syncthreads();
-  fft_lds<N, -1, Cg::CE>(lds_c + c * Cg::CS, j, tw_s);
-  fft_publish<Cg::CNT>();
+  cf v[Cg::CE];    // this thread's column at u = j + m * CNT
+  fft_fwd_open<N, Cg::CE>(lds_c + c * Cg::CS, j, tw_s, v);
   // largest component of the tile -> power-of-two scale that brings it into [16384, 32768)
-  cf v[Cg::NL][Cg::VW];
   float mx = 0.f;
 #pragma unroll
-  for (int m = 0; m < Cg::NL; ++m) {
-    const int idx = tid + m * Cg::NTH;
-    const int u = idx / Cg::CPR, c0 = (idx % Cg::CPR) * Cg::VW;
-#pragma unroll
-    for (int h = 0; h < Cg::VW; ++h) {
-      v[m][h] = lds_c[(c0 + h) * Cg::CS + padi<Cg::CE>(u)];
-      mx = fmaxf(mx, fmaxf(fabsf(v[m][h].x), fabsf(v[m][h].y)));
-    }
-  }
+  for (int m = 0; m < Cg::CE; ++m) mx = fmaxf(mx, fmaxf(fabsf(v[m].x), fabsf(v[m].y)));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
   if ((tid & 63) == 0) wmax[tid >> 6] = mx;
   __syncthreads();
   mx = 0.f;
-  for (int k = 0; k < Cg::NTH / 64; ++k) mx = fmaxf(mx, wmax[k]);
+  for (int k = 0; k < (Cg::NTH + 63) / 64; ++k) mx = fmaxf(mx, wmax[k]);
   int ex = 0;
   float sc = 1.f;
   if (mx > 0.f && mx < INFINITY) {
@@ -525,37 +612,24 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, FftGeom<N>::CWPS) 
   if (tid == 0) gscale[(size_t)frame * gs_stride + tile] = 1.0f / sc;
   h2* Gt = G + (size_t)frame * G_stride + (size_t)v0 * N;
 #pragma unroll
-  for (int m = 0; m < Cg::NL; ++m) {
-    const int idx = tid + m * Cg::NTH;
-    HC o;
+  for (int q = 0; q < Cg::NLG; ++q) {
+    h8 o;
 #pragma unroll
-    for (int h = 0; h < Cg::VW; ++h) {
-      const h2 q = to_h2(v[m][h] * (cf){sc, sc});
-      o[2 * h] = q.x;
-      o[2 * h + 1] = q.y;
+    for (int h = 0; h < 4; ++h) {
+      const h2 t = to_h2(v[4 * q + h] * (cf){sc, sc});
+      o[2 * h] = t.x;
+      o[2 * h + 1] = t.y;
     }
-    *reinterpret_cast<HC*>(Gt + (size_t)idx * Cg::VW) = o;
+    *reinterpret_cast<h8*>(Gt + ((size_t)q * Cg::NTH + tid) * 4) = o;
   }
 }
 
-#ifdef IAP_COL_STAMPS
-// development aid: cycles per phase of the column kernel, summed over the first wave of every workgroup
-__device__ unsigned long long g_col_stamps[16];
-#define CS_INIT() long long cs_last = clock64(), cs_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define CS_STAMP(i) do { long long t_ = clock64(); cs_acc[i] += t_ - cs_last; cs_last = t_; } while (0)
-#define CS_FLUSH() do { if (tid == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&g_col_stamps[i_], (unsigned long long)cs_acc[i_]); atomicAdd(&g_col_stamps[15], 1ull); } } while (0)
-#else
-#define CS_INIT() do {} while (0)
-#define CS_STAMP(i) do {} while (0)
-#define CS_FLUSH() do {} while (0)
-#endif
 template <int N>
 __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, FftGeom<N>::CWPS) void cols_xpower_kernel(
     const h2* __restrict__ F, long long F_stride, const h2* __restrict__ G, long long G_stride,
     const float* __restrict__ gscale, int gs_stride, cf* __restrict__ Q, long long Q_stride, int Wp, int nvalid,
     const cf* __restrict__ tw, int normalize, float scale, int ntiles, int nitems) {
   using Cg = ColGeom<N>;
-  typedef typename HChunk<Cg::VW>::T HC;
   extern __shared__ cf lds_c[];
   const int tid0 = threadIdx.x;
   __shared__ cf tw_s[FftGeom<N>::TWL];
@@ -566,8 +640,7 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, FftGeom<N>::CWPS) 
   // the forward FFT: the memory latency (most of a one-shot workgroup's life: of its 56 kcycles, 20 went to waiting
   // for F and 10 for G) runs under the FFTs.
   const int b = xcd_remap(blockIdx.x, gridDim.x);
-  CS_INIT();
-  HC fa[Cg::NL];
+  h8 fa[Cg::NL4];
   if (b < nitems) load_half_tile<N>(F + (size_t)(b / ntiles) * F_stride, Wp, (b % ntiles) * Cg::TC, tid0, fa);
   for (int item = b; item < nitems; item += gridDim.x) {
     const int f = item / ntiles, tile = item - f * ntiles, v0 = tile * Cg::TC;
@@ -576,12 +649,8 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, FftGeom<N>::CWPS) 
     int tid = tid0;
     asm volatile("" : "+v"(tid));
     const int c = tid / Cg::CNT, j = tid % Cg::CNT;
-    cf* s = lds_c + c * Cg::CS;
-    CS_STAMP(0);
     stage_half_tile<N>(lds_c, v0, nvalid, tid, fa);
-    CS_STAMP(1);
     __syncthreads();
-    CS_STAMP(2);
     {
       const int nx = item + gridDim.x;
       if (nx < nitems) load_half_tile<N>(F + (size_t)(nx / ntiles) * F_stride, Wp, (nx % ntiles) * Cg::TC, tid, fa);
@@ -590,49 +659,23 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, FftGeom<N>::CWPS) 
     const int gf = G_stride ? f : 0;
     const h2* Gt = G + (size_t)gf * G_stride + (size_t)v0 * N;
     const float sc = scale * gscale[(size_t)gf * gs_stride + tile];
-    HC g[Cg::NL];
+    h8 g[Cg::NLG];
 #pragma unroll
-#ifdef IAP_COL_X_NOG
-    for (int m = 0; m < Cg::NL; ++m) g[m] = *reinterpret_cast<const HC*>(G + (size_t)(tid & 63) * Cg::VW);
-#else
-    for (int m = 0; m < Cg::NL; ++m) g[m] = *reinterpret_cast<const HC*>(Gt + (size_t)(tid + m * Cg::NTH) * Cg::VW);
-#endif
-    fft_lds<N, -1, Cg::CE>(s, j, tw_s);
-    CS_STAMP(3);
+    for (int q = 0; q < Cg::NLG; ++q) g[q] = *reinterpret_cast<const h8*>(Gt + ((size_t)q * Cg::NTH + tid) * 4);
+    column_correlate<N>(lds_c + c * Cg::CS, j, tw_s,
+                        [&](int m) { return from_h2((h2){g[m >> 2][2 * (m & 3)], g[m >> 2][2 * (m & 3) + 1]}); }, sc,
+                        normalize, v0 + c == 0);
     fft_publish<Cg::CNT>();
-    CS_STAMP(4);
-#pragma unroll
-    for (int m = 0; m < Cg::NL; ++m) {
-      const int idx = tid + m * Cg::NTH;
-      const int u = idx / Cg::CPR, c0 = (idx % Cg::CPR) * Cg::VW;
-#pragma unroll
-      for (int h = 0; h < Cg::VW; ++h) {
-        const int at = (c0 + h) * Cg::CS + padi<Cg::CE>(u);
-        cf p = xpower(lds_c[at], from_h2((h2){g[m][2 * h], g[m][2 * h + 1]}), sc, normalize);
-        if (u == 0 && v0 + c0 + h == 0) p = mkc(0.f, 0.f);
-        lds_c[at] = p;
-      }
-    }
-    CS_STAMP(5);
-    __syncthreads();
-    CS_STAMP(6);
-    fft_lds<N, +1, Cg::CE>(s, j, tw_s);
-    CS_STAMP(7);
-    fft_publish<Cg::CNT>();
-    CS_STAMP(8);
     store_float_tile<N>(lds_c, Q + (size_t)f * Q_stride, Wp, v0, tid);
     __syncthreads();   // the tile is free for the next item
-    CS_STAMP(9);
   }
-  { const int tid = tid0; (void)tid; CS_FLUSH(); }
 }
 
 template <int N>
-__global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, FftGeom<N>::CE >= 32 ? 1 : 2) void cols_fused_kernel(
+__global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 2) void cols_fused_kernel(
     const h2* __restrict__ F, long long F_stride, const h2* __restrict__ Gref, long long G_stride,
     cf* __restrict__ Q, long long Q_stride, int Wp, int nvalid, const cf* __restrict__ tw, int normalize, float scale) {
   using Cg = ColGeom<N>;
-  typedef typename HChunk<Cg::VW>::T HC;
   extern __shared__ cf lds_c[];
   const int tid = threadIdx.x;
   const int c = tid / Cg::CNT, j = tid % Cg::CNT;
@@ -642,30 +685,18 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, FftGeom<N>::CE >= 
   __shared__ cf tw_s[FftGeom<N>::TWL];
   stage_twiddles<N>(tw_s, tw, tid);
   {
-    HC w[Cg::NL];
+    h8 w[Cg::NL4];
     load_half_tile<N>(F + (size_t)frame * F_stride, Wp, v0, tid, w);
     stage_half_tile<N>(lds_c, v0, nvalid, tid, w);
     load_half_tile<N>(Gref + (size_t)frame * G_stride, Wp, v0, tid, w);
     stage_half_tile<N>(lds_g, v0, nvalid, tid, w);
   }
   __syncthreads();
-  fft_lds<N, -1, Cg::CE>(lds_c + c * Cg::CS, j, tw_s);
+  // the reference's column transform ends in LDS; thread (c, j) then reads back its own column's values only
+  const cf* sg = lds_g + c * Cg::CS;
   fft_lds<N, -1, Cg::CE>(lds_g + c * Cg::CS, j, tw_s);
-  fft_publish<Cg::CNT>();
-#pragma unroll
-  for (int m = 0; m < Cg::NL; ++m) {
-    const int idx = tid + m * Cg::NTH;
-    const int u = idx / Cg::CPR, c0 = (idx % Cg::CPR) * Cg::VW;
-#pragma unroll
-    for (int h = 0; h < Cg::VW; ++h) {
-      const int at = (c0 + h) * Cg::CS + padi<Cg::CE>(u);
-      cf p = xpower(lds_c[at], lds_g[at], scale, normalize);
-      if (u == 0 && v0 + c0 + h == 0) p = mkc(0.f, 0.f);
-      lds_c[at] = p;
-    }
-  }
-  __syncthreads();
-  fft_lds<N, +1, Cg::CE>(lds_c + c * Cg::CS, j, tw_s);
+  column_correlate<N>(lds_c + c * Cg::CS, j, tw_s, [&](int m) { return sg[padi<Cg::CE>(j + m * Cg::CNT)]; }, scale,
+                      normalize, v0 + c == 0);
   fft_publish<Cg::CNT>();
   store_float_tile<N>(lds_c, Q + (size_t)frame * Q_stride, Wp, v0, tid);
 }
@@ -697,36 +728,46 @@ __device__ __forceinline__ void block_argmax(float& v, int& i, float* shv, int* 
 }
 
 template <int N>
-__global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_c2r_argmax_kernel(
+__global__ __launch_bounds__(FftGeom<N>::RPQ* FftGeom<N>::NT) void rows_c2r_argmax_kernel(
     const cf* __restrict__ Q, long long Q_stride, int Wp, const cf* __restrict__ tw, float* __restrict__ pval,
     int* __restrict__ pidx) {
   using Gm = FftGeom<N>;
+  constexpr int RP = Gm::RPQ, NTH = RP * Gm::NT, LG = Gm::NT < 32 ? Gm::NT : 32;
+  static_assert(RP % 2 == 0 && NTH % (LG * RP) == 0, "whole row quads, whole lane groups per pair");
   extern __shared__ cf lds_c[];
   __shared__ float shv[16];
   __shared__ int shi[16];
-  const int g = threadIdx.x / Gm::NT, j = threadIdx.x % Gm::NT;
+  const int t = threadIdx.x;
+  const int g = t / Gm::NT, j = t % Gm::NT;
   cf* s = lds_c + g * Gm::PADN;
-  const int pair = blockIdx.x * Gm::G + g;
-  const int ra = 2 * pair, rb = ra + 1;
-  const cf* Qa = Q + (size_t)blockIdx.y * Q_stride + (size_t)ra * Wp;
-  const cf* Qb = Qa + Wp;
-  // two neighbouring bins per lane and row as one 16-byte streaming load; the Nyquist bin on its own
-  auto put = [&](int k, cf a, cf b) {
-    if (k == 0 || k == N / 2) {  // c2r convention: the imaginary parts of the self-conjugate bins are ignored
-      a.y = 0.f;
-      b.y = 0.f;
-    }
-    s[padi<8>(k)] = mkc(a.x - b.y, a.y + b.x);
-    if (k > 0 && k < N / 2) s[padi<8>(N - k)] = mkc(a.x + b.y, b.x - a.y);
-  };
-  for (int k = 2 * j; k < N / 2; k += 2 * Gm::NT) {
+  const int ra = 2 * ((int)blockIdx.x * RP + g), rb = ra + 1;
+  {
+    // Q[.][v] holds the rows of a pair next to each other: one 16-byte streaming load brings both.  32 consecutive
+    // lanes take consecutive bins of one pair (conflict-free LDS stores), the groups of a wave the pairs of a quad,
+    // so that a wave reads whole lines.
+    const int lg = (t / LG) % RP;
+    const int yl = 2 * ((int)blockIdx.x * RP + lg);
+    cf* sl = lds_c + lg * Gm::PADN;
+    const cf* Qf = Q + (size_t)blockIdx.y * Q_stride;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    const f32x4 a2 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Qa + k));
-    const f32x4 b2 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Qb + k));
-    put(k, mkc(a2.x, a2.y), mkc(b2.x, b2.y));
-    put(k + 1, mkc(a2.z, a2.w), mkc(b2.z, b2.w));
+    auto put = [&](int k, f32x4 ab) {
+      cf a = mkc(ab.x, ab.y), b = mkc(ab.z, ab.w);
+      if (k == 0 || k == N / 2) {  // c2r convention: the imaginary parts of the self-conjugate bins are ignored
+        a.y = 0.f;
+        b.y = 0.f;
+      }
+      sl[padi<8>(k)] = mkc(a.x - b.y, a.y + b.x);
+      if (k > 0 && k < N / 2) sl[padi<8>(N - k)] = mkc(a.x + b.y, b.x - a.y);
+    };
+    const int k0 = (t % LG) + LG * (t / (LG * RP));   // < NT = N / 8: four rounds cover the bins below Nyquist
+    f32x4 ab[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      ab[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Qf + q_at(yl, k0 + i * Gm::NT, Wp)));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) put(k0 + i * Gm::NT, ab[i]);
+    if (k0 == 0) put(N / 2, __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Qf + q_at(yl, N / 2, Wp))));
   }
-  if (j == 0) put(N / 2, load_cf_nt(Qa + N / 2), load_cf_nt(Qb + N / 2));
   __syncthreads();
   fft_lds<N, +1>(s, j, tw);
   float bv = -INFINITY;
@@ -888,7 +929,7 @@ __global__ __launch_bounds__(256) void upsample_tables_kernel(int Py, int Px, in
 #pragma unroll
   for (int j = 0; j <= UP_N; ++j) acc[j] = (v2f){0.f, 0.f};
   if (i < Py) {
-    const cf q = Q[(size_t)frame * Q_stride + (size_t)i * Wp + Px / 2];
+    const cf q = Q[(size_t)frame * Q_stride + q_at(i, Px / 2, Wp)];
     const int n = cs.x - i;
     double sa, ca;
     sincospi((double)n / (double)Py, &sa, &ca);
@@ -974,36 +1015,44 @@ __global__ __launch_bounds__(256) void upsample_partial_kernel(const cf* __restr
   for (int c = 0; c < 2; ++c)
 #pragma unroll
     for (int j = 0; j <= UP_N; ++j) acc[c][j] = (v2f){0.f, 0.f};
-  const cf* Rp[2];
-#pragma unroll
-  for (int c = 0; c < 2; ++c) Rp[c] = R + (size_t)frame * R_stride + (size_t)u0 * Wp + (ok[c] ? vcol[c] : 0);
-  const float* __restrict__ yr = yrec + ((size_t)frame * Py + u0) * UP_YS;
-  constexpr int PF = 4;  // rows in flight: the next group's loads are issued before this group's FMAs
-  cf r[2][PF], rn[2][PF];
+  // this thread's columns in the row-interleaved Q: the 4 rows of a block are 32 contiguous bytes
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const f32x4* Rp[2];
 #pragma unroll
   for (int c = 0; c < 2; ++c)
+    Rp[c] = reinterpret_cast<const f32x4*>(R + (size_t)frame * R_stride + q_at(u0, ok[c] ? vcol[c] : 0, Wp));   // 4 | u0
+  const size_t rblk = (size_t)Wp * 2;   // f32x4 units per 4-row block
+  const float* __restrict__ yr = yrec + ((size_t)frame * Py + u0) * UP_YS;
+  constexpr int PF = 4;  // rows in flight = one block: the next block's loads are issued before this block's FMAs
+  f32x4 r[2][2], rn[2][2];
 #pragma unroll
-    for (int i = 0; i < PF; ++i) r[c][i] = Rp[c][(size_t)i * Wp];
+  for (int c = 0; c < 2; ++c) {
+    r[c][0] = Rp[c][0];
+    r[c][1] = Rp[c][1];
+  }
   for (int ul = 0; ul < len; ul += PF) {
     const int un = min(ul + PF, len - PF);
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int i = 0; i < PF; ++i) rn[c][i] = Rp[c][(size_t)(un + i) * Wp];
+    for (int c = 0; c < 2; ++c) {
+      rn[c][0] = Rp[c][(size_t)(un >> 2) * rblk];
+      rn[c][1] = Rp[c][(size_t)(un >> 2) * rblk + 1];
+    }
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       const float* __restrict__ rec = yr + (ul + i) * UP_YS;
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        const v2f q = {r[c][i].x, r[c][i].y};
+        const f32x4 two = r[c][i >> 1];
+        const v2f q = (i & 1) ? (v2f){two.z, two.w} : (v2f){two.x, two.y};
 #pragma unroll
         for (int j = 0; j <= UP_N; ++j) acc[c][j] = __builtin_elementwise_fma(q, (v2f){rec[j], rec[j]}, acc[c][j]);
       }
     }
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int i = 0; i < PF; ++i) r[c][i] = rn[c][i];
+    for (int c = 0; c < 2; ++c) {
+      r[c][0] = rn[c][0];
+      r[c][1] = rn[c][1];
+    }
   }
 #ifdef IAP_UP_STAMPS
   const long long t_main = wall_clock64();
@@ -1616,18 +1665,16 @@ static int fft_window(int n) {
 struct RegPlan {
   int Y, X, Py, Px, oy, ox, Wp;
   size_t spec;      // complex elements per spectrum
-  int row_blocks;   // workgroups of the row kernels per frame (= arg-max partials)
+  int row_blocks;   // workgroups of the inverse row kernel per frame (= arg-max partials)
   int col_blocks;
   int ncg, nuc;     // upsample chunks: column groups x row chunks
 };
 
-template <int N>
-static int rows_G() { return FftGeom<N>::G; }
-
-static int geom_rows_G(int N) {
+// row pairs per workgroup of the inverse row kernel (FftGeom<N>::RPQ)
+static int geom_rows_RPQ(int N) {
   int nt = N / 8;
   int g = 256 / nt;
-  return g > 1 ? g : 1;
+  return g > 2 ? g : 2;
 }
 static int geom_TC(int N) { return (8192 / N) < 16 ? (8192 / N) : 16; }
 
@@ -1641,7 +1688,7 @@ static bool make_plan(int Y, int X, RegPlan& p) {
   p.ox = (X - p.Px) / 2;
   p.Wp = (p.Px / 2 + 1 + 15) / 16 * 16;
   p.spec = (size_t)p.Py * p.Wp;
-  p.row_blocks = p.Py / 2 / geom_rows_G(p.Px);
+  p.row_blocks = p.Py / 2 / geom_rows_RPQ(p.Px);
   p.col_blocks = p.Wp / geom_TC(p.Py);
   p.ncg = (p.Px / 2 + 511) / 512;
   p.nuc = std::max(1, p.Py / UP_UB_MIN);  // most row chunks a launch may use (sizes the partials)
@@ -1743,15 +1790,17 @@ static int launch_rows_r2c(const RegPlan& p, const void* src, int kind, long lon
   const int vec = kind == 0 && aligned16(src) && p.X % 8 == 0 && p.ox % 8 == 0 && plane_stride % 8 == 0;
   IAP_FOR_N(p.Px, {
     using Gm = FftGeom<N>;
-    size_t lds = (size_t)Gm::G * Gm::PADN * sizeof(cf);
     ProfScope ps_(K_ROWS_R2C, st);
     if (half16) {
+      static_assert(FftGeom<N>::RPQ == (256 / (N / 8) > 2 ? 256 / (N / 8) : 2), "geom_rows_RPQ");
+      const size_t lds = (size_t)Gm::RP16 * Gm::PADN * sizeof(cf);
       IAP_HIP(allow_lds((rows_r2c_kernel<N, true>), lds));
-      hipLaunchKernelGGL((rows_r2c_kernel<N, true>), dim3(p.row_blocks, n), dim3(Gm::G * Gm::NT), lds, st, src, kind,
-                         plane_stride, p.X, p.oy, p.ox, in_scale, F, F_stride, p.Wp, tw_x, vec, sub.sub2, sub.stride);
+      hipLaunchKernelGGL((rows_r2c_kernel<N, true>), dim3(p.Py / 2 / Gm::RP16, n), dim3(Gm::RP16 * Gm::NT), lds, st, src,
+                         kind, plane_stride, p.X, p.oy, p.ox, in_scale, F, F_stride, p.Wp, tw_x, vec, sub.sub2, sub.stride);
     } else {
+      const size_t lds = (size_t)Gm::G * Gm::PADN * sizeof(cf);
       IAP_HIP(allow_lds((rows_r2c_kernel<N, false>), lds));
-      hipLaunchKernelGGL((rows_r2c_kernel<N, false>), dim3(p.row_blocks, n), dim3(Gm::G * Gm::NT), lds, st, src, kind,
+      hipLaunchKernelGGL((rows_r2c_kernel<N, false>), dim3(p.Py / 2 / Gm::G, n), dim3(Gm::G * Gm::NT), lds, st, src, kind,
                          plane_stride, p.X, p.oy, p.ox, in_scale, F, F_stride, p.Wp, tw_x, vec, sub.sub2, sub.stride);
     }
   });
@@ -1779,15 +1828,16 @@ static int launch_cols_ref(const RegPlan& p, const cf* F, long long F_stride, h2
 }
 
 // n moving frames (half row spectra F) against G (one for all: G_stride 0, or one per frame) -> Q (float)
-// workgroups of a column kernel that are resident at once on this device (0 on error)
-template <typename K>
-static int cols_resident(K kernel, int threads, size_t lds) {
-  static std::atomic<int> known[64];          // per kernel instantiation and device; the queries are slow
+// workgroups of cols_xpower_kernel<N> that are resident at once on this device (0 on error); one cache per plane
+// size and device, the queries are slow
+template <int N>
+static int cols_resident(int threads, size_t lds) {
+  static std::atomic<int> known[64];
   int per_cu = 0, dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 0;
   if (dev >= 0 && dev < 64 && known[dev].load() > 0) return known[dev].load();
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cols_xpower_kernel<N>, threads, lds) != hipSuccess) return 0;
   if (dev >= 0 && dev < 64) known[dev].store(per_cu * cus);
   return per_cu * cus;
 }
@@ -1803,7 +1853,7 @@ static int launch_cols_xpower(const RegPlan& p, const h2* F, const h2* G, long l
     ProfScope ps_(K_COLS, st);
     const long long items = (long long)valid_tiles(p) * n;
     if (items > 0x7fffffffLL) return IAP_E_UNSUPPORTED;
-    const int resident = cols_resident(cols_xpower_kernel<N>, Gm::TC * Gm::CNT, lds);
+    const int resident = cols_resident<N>(Gm::TC * Gm::CNT, lds);
     if (resident < 1) return (int)hipErrorUnknown;
     hipLaunchKernelGGL(cols_xpower_kernel<N>, dim3((unsigned)std::min<long long>(items, resident)), dim3(Gm::TC * Gm::CNT),
                        lds, st, F, spec16_stride(p), G, G_stride, gscale, p.col_blocks, Q, spec32_stride(p), p.Wp,
@@ -1833,9 +1883,9 @@ static int launch_rows_c2r(const RegPlan& p, const cf* Q, long long Q_stride, in
                            int* pidx, hipStream_t st) {
   IAP_FOR_N(p.Px, {
     using Gm = FftGeom<N>;
-    size_t lds = (size_t)Gm::G * Gm::PADN * sizeof(cf);
+    size_t lds = (size_t)Gm::RPQ * Gm::PADN * sizeof(cf);
     IAP_HIP(allow_lds(rows_c2r_argmax_kernel<N>, lds));
-    { ProfScope ps_(K_ROWS_C2R, st); hipLaunchKernelGGL(rows_c2r_argmax_kernel<N>, dim3(p.row_blocks, n), dim3(Gm::G * Gm::NT), lds, st, Q, Q_stride,
+    { ProfScope ps_(K_ROWS_C2R, st); hipLaunchKernelGGL(rows_c2r_argmax_kernel<N>, dim3(p.row_blocks, n), dim3(Gm::RPQ * Gm::NT), lds, st, Q, Q_stride,
                        p.Wp, tw_x, pval, pidx); }
   });
   IAP_LAUNCH_CHECK();
@@ -1958,14 +2008,6 @@ static int launch_apply(const uint16_t* in, uint16_t* out, long long n_frames, l
 }  // namespace iap
 
 using namespace iap;
-
-#ifdef IAP_COL_STAMPS
-extern "C" void iap_debug_col_stamps(unsigned long long* host16) {
-  (void)hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_col_stamps), 16 * sizeof(unsigned long long));
-  unsigned long long z[16] = {0};
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_col_stamps), z, sizeof(z));
-}
-#endif
 
 #ifdef IAP_AP_STAMPS
 extern "C" void iap_debug_ap_stamps(unsigned long long* host8) {
