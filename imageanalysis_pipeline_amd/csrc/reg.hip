@@ -325,9 +325,7 @@ struct FftGeom {
   // LDS stride between columns: the padded column (N + N/16 for 16 points per thread) rounded up to 1 mod 16, so
   // that the 16 lanes that stage 4-row pieces of 4 columns x 2 half blocks x 2 blocks hit 16 different bank pairs
   static constexpr int CS = ((CE >= 16 ? N + N / 16 : PADN) + 15) / 16 * 16 + 1;
-  // Row pairs per workgroup of the row kernels that write / read the row-interleaved spectra (below): 8 rows
-  // (a whole 128-byte line per 4-column tile of F) where 1024 threads allow it, at least 4 rows (Q's interleave).
-  static constexpr int RP16 = NT >= 512 ? 2 : (G >= 4 ? G : 4);
+  // row pairs per workgroup of the inverse row kernel: at least the 4 rows of Q's interleave (below)
   static constexpr int RPQ = G >= 2 ? G : 2;
 };
 
@@ -382,86 +380,146 @@ __device__ __forceinline__ h2 to_h2(cf v) { return __builtin_convertvector(v, h2
 __device__ __forceinline__ cf from_h2(h2 v) { return __builtin_convertvector(v, cf); }
 template <int N> constexpr float fs16() { return 0.5f / (float)N; }
 
-template <int N, bool OUT16>
-__global__ __launch_bounds__((OUT16 ? FftGeom<N>::RP16 : FftGeom<N>::G) * FftGeom<N>::NT) void rows_r2c_kernel(
+// two real rows per complex transform: Fa[k] = (Z[k] + conj Z[N-k]) / 2, Fb[k] = (Z[k] - conj Z[N-k]) / 2i
+template <int N>
+__device__ __forceinline__ void split_rows(const cf* sp, int k, cf& fa, cf& fb) {
+  const cf zk = sp[padi<8>(k)], zn = sp[padi<8>((N - k) & (N - 1))];
+  fa = mkc(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+  fb = mkc(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+}
+
+// the reference plane (any source kind): float row spectrum, row-major
+template <int N>
+__global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_r2c_kernel(
     const void* __restrict__ src, int kind, long long plane_stride, int srcX, int oy, int ox, float in_scale,
-    void* __restrict__ Fv, long long F_stride, int Wp, const cf* __restrict__ tw, int vec,
-    const int* __restrict__ sub2, long long sub_stride) {
+    cf* __restrict__ F, long long F_stride, int Wp, const cf* __restrict__ tw, const int* __restrict__ sub2,
+    long long sub_stride) {
   using Gm = FftGeom<N>;
-  constexpr int RP = OUT16 ? Gm::RP16 : Gm::G;   // row pairs per workgroup
   extern __shared__ cf lds_c[];
   const int g = threadIdx.x / Gm::NT, j = threadIdx.x % Gm::NT;
   cf* s = lds_c + g * Gm::PADN;
-  const int pair = blockIdx.x * RP + g;
-  const int ra = 2 * pair;
+  const int ra = 2 * (blockIdx.x * Gm::G + g);
   const int lv = kind == 0 ? plane_level(sub2, (long long)blockIdx.y * sub_stride) : 0;   // u16 sources only
-  const size_t base = (size_t)blockIdx.y * plane_stride;
-  const size_t offa = base + (size_t)(oy + ra) * srcX + ox;
+  const size_t offa = (size_t)blockIdx.y * plane_stride + (size_t)(oy + ra) * srcX + ox;
   const size_t offb = offa + srcX;
-  if (OUT16) in_scale *= fs16<N>();
-  if (vec) {  // u16 source, 16-byte aligned rows: one 8-pixel vector per row and thread
-    const uint16_t* p16 = reinterpret_cast<const uint16_t*>(src);
-    u16x8 qa = load8(p16 + offa + 8 * j), qb = load8(p16 + offb + 8 * j);
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      s[padi<8>(8 * j + k)] = mkc((float)max((int)qa.v[k] - lv, 0) * in_scale, (float)max((int)qb.v[k] - lv, 0) * in_scale);
-  } else {
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      int n = j + m * Gm::NT;
-      // (exact in f32: pixel values and levels are integers below 2^16)
-      float a = load_src(src, kind, offa + n), b = load_src(src, kind, offb + n);
-      if (kind == 0) {
-        a = fmaxf(a - (float)lv, 0.f);
-        b = fmaxf(b - (float)lv, 0.f);
-      }
-      s[padi<8>(n)] = mkc(a * in_scale, b * in_scale);
+  for (int m = 0; m < 8; ++m) {
+    int n = j + m * Gm::NT;
+    // (exact in f32: pixel values and levels are integers below 2^16)
+    float a = load_src(src, kind, offa + n), b = load_src(src, kind, offb + n);
+    if (kind == 0) {
+      a = fmaxf(a - (float)lv, 0.f);
+      b = fmaxf(b - (float)lv, 0.f);
     }
+    s[padi<8>(n)] = mkc(a * in_scale, b * in_scale);
   }
   __syncthreads();
   fft_lds<N, -1>(s, j, tw);
-  // two real rows per complex transform: Fa[k] = (Z[k] + conj Z[N-k]) / 2, Fb[k] = (Z[k] - conj Z[N-k]) / 2i
-  auto split = [&](const cf* sp, int k, cf& fa, cf& fb) {
-    const cf zk = sp[padi<8>(k)], zn = sp[padi<8>((N - k) & (N - 1))];
-    fa = mkc(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-    fb = mkc(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+  cf* Fa = F + (size_t)blockIdx.y * F_stride + (size_t)ra * Wp;
+  cf* Fb = Fa + Wp;
+  for (int k = j; k <= N / 2; k += Gm::NT) {
+    cf fa, fb;
+    split_rows<N>(s, k, fa, fb);
+    Fa[k] = fa;
+    Fb[k] = fb;
+  }
+}
+
+// The moving planes (u16): half-pair row spectra in the row-interleaved layout.  A workgroup produces whole 8-row
+// blocks.  Where a transform takes 128 threads or more it does so in two steps of two row pairs each: the first
+// step's results wait in registers (16 bytes per thread and round) while the second step's rows, requested before
+// the first transform started, go through the same LDS, and both leave together as 32 contiguous bytes per column --
+// whole lines from one wave, with the workgroups as small as the transforms allow (four per CU at 2048 points).
+template <int N>
+struct R16Geom {
+  using Gm = FftGeom<N>;
+  static constexpr int PS = Gm::G >= 4 ? Gm::G : 2;      // row pairs per step
+  static constexpr int STEPS = Gm::G >= 4 ? 1 : 2;
+  static constexpr int NTH = PS * Gm::NT;
+  static constexpr int ROWS = 2 * PS * STEPS;            // rows per workgroup: a multiple of 8
+  static constexpr int NQ = PS / 2;                      // row quads per step
+  static constexpr int LG = NTH / NQ < 32 ? NTH / NQ : 32;
+  static constexpr int KSTEP = NTH / NQ;                 // = 2 NT = N / 4: two rounds cover the bins below Nyquist
+  static_assert(ROWS % 8 == 0 && NTH % (LG * NQ) == 0 && KSTEP * 2 == N / 2, "row blocks, lane groups, rounds");
+};
+template <int N, bool vec>
+__global__ __launch_bounds__(R16Geom<N>::NTH, 8) void rows_r2c16_kernel(
+    const uint16_t* __restrict__ src, long long plane_stride, int srcX, int oy, int ox, h2* __restrict__ F,
+    long long F_stride, int Wp, const cf* __restrict__ tw, const int* __restrict__ sub2, long long sub_stride) {
+  using Gm = FftGeom<N>;
+  using Rg = R16Geom<N>;
+  extern __shared__ cf lds_c[];
+  const int t = threadIdx.x;
+  const int g = t / Gm::NT;
+  int j = t % Gm::NT;
+  cf* s = lds_c + g * Gm::PADN;
+  const int r0 = blockIdx.x * Rg::ROWS;
+  const int lv = plane_level(sub2, (long long)blockIdx.y * sub_stride);
+  const float in_scale = fs16<N>();
+  const uint16_t* p = src + (size_t)blockIdx.y * plane_stride + (size_t)oy * srcX + ox;
+  auto row_of = [&](int step) { return r0 + step * 2 * Rg::PS + 2 * g; };
+  // 16-byte aligned rows: one 8-pixel vector per row and thread, fetched a step ahead
+  auto fetch = [&](int step, u16x8& qa, u16x8& qb) {
+    const uint16_t* pa = p + (size_t)row_of(step) * srcX + 8 * j;
+    qa = load8(pa);
+    qb = load8(pa + srcX);
   };
-  if constexpr (OUT16) {
-    // 4 rows (two pairs) of one column per 16-byte store; 32 consecutive lanes take consecutive columns of one
-    // row quad (conflict-free LDS reads), the lanes 32 apart the other quad of the same 8-row block: a wave's
-    // store is one contiguous run of whole lines
-    static_assert(RP % 2 == 0, "whole row quads");
-    fft_publish<Gm::NT>();   // the quads are read across the transforms' own thread groups
-    constexpr int NQ = RP / 2, NTH = RP * Gm::NT, LG = NTH / NQ < 32 ? NTH / NQ : 32, KSTEP = LG * (NTH / (LG * NQ));
-    static_assert(NTH % (LG * NQ) == 0, "whole lane groups per quad");
-    const int t = threadIdx.x;
-    const int q = (t / LG) % NQ;
-    const int y0 = (int)blockIdx.x * 2 * RP + 4 * q;
-    h2* Fo = reinterpret_cast<h2*>(Fv) + (size_t)blockIdx.y * F_stride;
-    const cf* sa = lds_c + (2 * q) * Gm::PADN;
-    const cf* sb = sa + Gm::PADN;
-    auto emit = [&](int k) {
-      cf f0, f1, f2, f3;
-      split(sa, k, f0, f1);
-      split(sb, k, f2, f3);
-      const h2 h0 = to_h2(f0), h1 = to_h2(f1), h2_ = to_h2(f2), h3 = to_h2(f3);
-      h8 o = {h0.x, h0.y, h1.x, h1.y, h2_.x, h2_.y, h3.x, h3.y};
-      *reinterpret_cast<h8*>(Fo + f_at(y0, k, Wp)) = o;
-    };
-    const int k0 = (t % LG) + LG * (t / (LG * NQ));   // < KSTEP = 2 NT = N / 4
-    static_assert(KSTEP * 2 == N / 2, "two rounds cover the bins below Nyquist");
-    emit(k0);
-    emit(k0 + KSTEP);
-    if (k0 == 0) emit(N / 2);
-  } else {
-    cf* Fa = reinterpret_cast<cf*>(Fv) + (size_t)blockIdx.y * F_stride + (size_t)ra * Wp;
-    cf* Fb = Fa + Wp;
-    for (int k = j; k <= N / 2; k += Gm::NT) {
-      cf fa, fb;
-      split(s, k, fa, fb);
-      Fa[k] = fa;
-      Fb[k] = fb;
+  auto stage = [&](int step, const u16x8& qa, const u16x8& qb) {
+    if (vec) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        s[padi<8>(8 * j + k)] = mkc((float)max((int)qa.v[k] - lv, 0) * in_scale, (float)max((int)qb.v[k] - lv, 0) * in_scale);
+    } else {
+      const uint16_t* pa = p + (size_t)row_of(step) * srcX;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int n = j + m * Gm::NT;
+        s[padi<8>(n)] = mkc((float)max((int)pa[n] - lv, 0) * in_scale, (float)max((int)pa[srcX + n] - lv, 0) * in_scale);
+      }
     }
+  };
+  // 4 rows (two pairs) of one column as 8 halves; 32 consecutive lanes take consecutive columns of one row quad
+  // (conflict-free LDS reads)
+  const int q = (t / Rg::LG) % Rg::NQ;
+  const int k0 = (t % Rg::LG) + Rg::LG * (t / (Rg::LG * Rg::NQ));   // < KSTEP
+  const cf* sa = lds_c + (2 * q) * Gm::PADN;
+  const cf* sb = sa + Gm::PADN;
+  auto quad = [&](int k) {
+    cf f0, f1, f2, f3;
+    split_rows<N>(sa, k, f0, f1);
+    split_rows<N>(sb, k, f2, f3);
+    const h2 h0 = to_h2(f0), h1 = to_h2(f1), h2_ = to_h2(f2), h3 = to_h2(f3);
+    return (h8){h0.x, h0.y, h1.x, h1.y, h2_.x, h2_.y, h3.x, h3.y};
+  };
+  h2* Fo = F + (size_t)blockIdx.y * F_stride;
+  u16x8 qa, qb;
+  if (vec) fetch(0, qa, qb);
+  stage(0, qa, qb);
+  __syncthreads();
+  if (Rg::STEPS == 2 && vec) fetch(1, qa, qb);
+  fft_lds<N, -1>(s, j, tw);
+  fft_publish<Gm::NT>();   // the quads are read across the transforms' own thread groups
+  if constexpr (Rg::STEPS == 1) {
+    const int y0 = r0 + 4 * q;
+    *reinterpret_cast<h8*>(Fo + f_at(y0, k0, Wp)) = quad(k0);
+    *reinterpret_cast<h8*>(Fo + f_at(y0, k0 + Rg::KSTEP, Wp)) = quad(k0 + Rg::KSTEP);
+    if (k0 == 0) *reinterpret_cast<h8*>(Fo + f_at(y0, N / 2, Wp)) = quad(N / 2);
+  } else {
+    static_assert(Rg::STEPS == 1 || Rg::NQ == 1, "two steps: one quad per step");
+    const h8 a0 = quad(k0), a1 = quad(k0 + Rg::KSTEP);
+    h2* o = Fo + f_at(r0, k0, Wp);          // rows r0 .. r0 + 3 of column k0, rows r0 + 4 .. + 7 behind them
+    if (k0 == 0) *reinterpret_cast<h8*>(o + (size_t)(N / 2) * 8) = quad(N / 2);   // (the Nyquist column: half lines)
+    __syncthreads();   // the first step's spectra are in registers
+    stage(1, qa, qb);
+    __syncthreads();
+    asm volatile("" : "+v"(j));   // the second transform works out its LDS offsets anew instead of holding the first one's
+    fft_lds<N, -1>(s, j, tw);
+    fft_publish<Gm::NT>();
+    *reinterpret_cast<h8*>(o) = a0;
+    *reinterpret_cast<h8*>(o + 4) = quad(k0);
+    *reinterpret_cast<h8*>(o + (size_t)Rg::KSTEP * 8) = a1;
+    *reinterpret_cast<h8*>(o + (size_t)Rg::KSTEP * 8 + 4) = quad(k0 + Rg::KSTEP);
+    if (k0 == 0) *reinterpret_cast<h8*>(o + (size_t)(N / 2) * 8 + 4) = quad(N / 2);
   }
 }
 
@@ -1793,15 +1851,23 @@ static int launch_rows_r2c(const RegPlan& p, const void* src, int kind, long lon
     ProfScope ps_(K_ROWS_R2C, st);
     if (half16) {
       static_assert(FftGeom<N>::RPQ == (256 / (N / 8) > 2 ? 256 / (N / 8) : 2), "geom_rows_RPQ");
-      const size_t lds = (size_t)Gm::RP16 * Gm::PADN * sizeof(cf);
-      IAP_HIP(allow_lds((rows_r2c_kernel<N, true>), lds));
-      hipLaunchKernelGGL((rows_r2c_kernel<N, true>), dim3(p.Py / 2 / Gm::RP16, n), dim3(Gm::RP16 * Gm::NT), lds, st, src,
-                         kind, plane_stride, p.X, p.oy, p.ox, in_scale, F, F_stride, p.Wp, tw_x, vec, sub.sub2, sub.stride);
+      using Rg = R16Geom<N>;
+      if (kind != 0 || in_scale != 1.0f) return IAP_E_ARG;   // the moving planes are u16
+      const size_t lds = (size_t)Rg::PS * Gm::PADN * sizeof(cf);
+      if (vec) {
+        IAP_HIP(allow_lds((rows_r2c16_kernel<N, true>), lds));
+        hipLaunchKernelGGL((rows_r2c16_kernel<N, true>), dim3(p.Py / Rg::ROWS, n), dim3(Rg::NTH), lds, st, (const uint16_t*)src,
+                           plane_stride, p.X, p.oy, p.ox, (h2*)F, F_stride, p.Wp, tw_x, sub.sub2, sub.stride);
+      } else {
+        IAP_HIP(allow_lds((rows_r2c16_kernel<N, false>), lds));
+        hipLaunchKernelGGL((rows_r2c16_kernel<N, false>), dim3(p.Py / Rg::ROWS, n), dim3(Rg::NTH), lds, st, (const uint16_t*)src,
+                           plane_stride, p.X, p.oy, p.ox, (h2*)F, F_stride, p.Wp, tw_x, sub.sub2, sub.stride);
+      }
     } else {
       const size_t lds = (size_t)Gm::G * Gm::PADN * sizeof(cf);
-      IAP_HIP(allow_lds((rows_r2c_kernel<N, false>), lds));
-      hipLaunchKernelGGL((rows_r2c_kernel<N, false>), dim3(p.Py / 2 / Gm::G, n), dim3(Gm::G * Gm::NT), lds, st, src, kind,
-                         plane_stride, p.X, p.oy, p.ox, in_scale, F, F_stride, p.Wp, tw_x, vec, sub.sub2, sub.stride);
+      IAP_HIP(allow_lds(rows_r2c_kernel<N>, lds));
+      hipLaunchKernelGGL(rows_r2c_kernel<N>, dim3(p.Py / 2 / Gm::G, n), dim3(Gm::G * Gm::NT), lds, st, src, kind,
+                         plane_stride, p.X, p.oy, p.ox, in_scale, (cf*)F, F_stride, p.Wp, tw_x, sub.sub2, sub.stride);
     }
   });
   IAP_LAUNCH_CHECK();
