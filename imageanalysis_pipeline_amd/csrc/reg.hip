@@ -562,7 +562,8 @@ __device__ __forceinline__ void load_half_tile(const h2* __restrict__ Ff, int Wp
 #pragma unroll
   for (int m = 0; m < Cg::NL4; ++m) {
     const int idx = tid + m * Cg::NTH;
-    w[m] = *reinterpret_cast<const h8*>(Ff + ((size_t)(idx / (2 * Cg::TC)) * Wp + v0) * 8 + (idx % (2 * Cg::TC)) * 4);
+    // (streaming: a line of F is used once, by this tile)
+    w[m] = __builtin_nontemporal_load(reinterpret_cast<const h8*>(Ff + ((size_t)(idx / (2 * Cg::TC)) * Wp + v0) * 8 + (idx % (2 * Cg::TC)) * 4));
   }
 }
 template <int N>
@@ -572,36 +573,51 @@ __device__ __forceinline__ void stage_half_tile(cf* lds, int v0, int nvalid, int
   for (int m = 0; m < Cg::NL4; ++m) {
     const int idx = tid + m * Cg::NTH;
     const int wi = idx % (2 * Cg::TC), c = wi >> 1, u0 = (idx / (2 * Cg::TC)) * 8 + (wi & 1) * 4;
-    const bool ok = v0 + c < nvalid;   // padding columns hold whatever the workspace held
     cf* d = lds + c * Cg::CS;
+    if (v0 + Cg::TC <= nvalid) {   // (uniform) every tile but the last
 #pragma unroll
-    for (int h = 0; h < 4; ++h)   // (16 points per thread: 4 | u0, the four rows share a pad group and are contiguous)
-      d[padi<Cg::CE>(u0 + h)] = ok ? from_h2((h2){w[m][2 * h], w[m][2 * h + 1]}) : mkc(0.f, 0.f);
+      for (int h = 0; h < 4; ++h)   // (16 points per thread: 4 | u0, the four rows share a pad group and are contiguous)
+        d[padi<Cg::CE>(u0 + h)] = from_h2((h2){w[m][2 * h], w[m][2 * h + 1]});
+    } else {
+      const bool ok = v0 + c < nvalid;   // padding columns hold whatever the workspace held
+#pragma unroll
+      for (int h = 0; h < 4; ++h) d[padi<Cg::CE>(u0 + h)] = ok ? from_h2((h2){w[m][2 * h], w[m][2 * h + 1]}) : mkc(0.f, 0.f);
+    }
   }
 }
 // Q tile (LDS) -> row-interleaved float spectrum: two rows of one column per 16-byte store, the tile's share of a
-// 4-row block is TC * 2 contiguous chunks
+// 4-row block is TC * 2 contiguous chunks.  A wave stores 64 consecutive chunks (whole lines); which lane takes
+// which of them is free, and for 4-column tiles the lanes are dealt so that each half wave reads two columns x
+// 8 blocks x 2 row pairs = 32 different bank pairs (in chunk order columns 0 and 2 would collide).
 template <int N>
 __device__ __forceinline__ void store_float_tile(const cf* lds, cf* __restrict__ Qf, int Wp, int v0, int tid) {
   using Cg = ColGeom<N>;
 #pragma unroll 4
   for (int m = 0; m < Cg::CE / 2; ++m) {
-    const int idx = tid + m * Cg::NTH;
+    int idx = tid + m * Cg::NTH;
+    if constexpr (Cg::TC == 4) {
+      const int l = idx & 63;
+      idx = (idx & ~63) + ((l >> 2) & 7) * 8 + ((l >> 5) * 2 + (l & 1)) * 2 + ((l >> 1) & 1);
+    }
     const int wi = idx % (2 * Cg::TC), c = wi >> 1, u = (idx / (2 * Cg::TC)) * 4 + (wi & 1) * 2;
     const cf* sp = lds + c * Cg::CS;
     const cf a = sp[padi<Cg::CE>(u)], b2 = sp[padi<Cg::CE>(u + 1)];
     *reinterpret_cast<float4*>(Qf + ((size_t)(idx / (2 * Cg::TC)) * Wp + v0) * 4 + wi * 2) = make_float4(a.x, a.y, b2.x, b2.y);
   }
 }
-__device__ __forceinline__ cf xpower(cf g, cf f, float scale, int normalize) {
-  cf p = mkc((f.x * g.x + f.y * g.y) * scale, (f.y * g.x - f.x * g.y) * scale);   // f conj(g): g = the moving frame's value, f = the reference's
-  if (normalize) {
-    float m2 = p.x * p.x + p.y * p.y;
-    float inv = m2 > 0.f ? rsqrtf(m2) : 0.f;
-    p.x *= inv;
-    p.y *= inv;
-  }
-  return p;
+// f conj(g) * scale (g = the moving frame's value, f = the reference's) as three packed instructions:
+// (g.x, g.x) f, then + (g.y, g.y) (f.y, -f.x) -- the half selects and the sign ride in the second one
+__device__ __forceinline__ cf xpower(cf g, cf f, float scale) {
+  const cf t = (cf){g.x, g.x} * f;
+  cf r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(g), "v"(f), "v"(t));
+  return r * (cf){scale, scale};
+}
+// optional whitening P / |P| (IAP_REG_NORMALIZE)
+__device__ __forceinline__ cf unit_or_zero(cf p) {
+  const float m2 = p.x * p.x + p.y * p.y;
+  const float inv = m2 > 0.f ? rsqrtf(m2) : 0.f;
+  return p * (cf){inv, inv};
 }
 // One column of the tile, already staged in LDS: forward FFT, times the reference (ref(m) = its value at
 // u = j + m * CNT), DC zeroed, inverse FFT back into the same LDS column.
@@ -612,7 +628,11 @@ __device__ __forceinline__ void column_correlate(cf* s, int j, const cf* __restr
   cf x[Cg::CE];
   fft_fwd_open<N, Cg::CE>(s, j, tw_s, x);
 #pragma unroll
-  for (int m = 0; m < Cg::CE; ++m) x[m] = xpower(x[m], ref(m), sc, normalize);
+  for (int m = 0; m < Cg::CE; ++m) x[m] = xpower(x[m], ref(m), sc);
+  if (normalize) {   // (uniform)
+#pragma unroll
+    for (int m = 0; m < Cg::CE; ++m) x[m] = unit_or_zero(x[m]);
+  }
   if (dc_column && j == 0) x[0] = mkc(0.f, 0.f);
   fft_inv_regs<N, Cg::CE>(s, j, tw_s, x);
 }
@@ -697,9 +717,16 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, FftGeom<N>::CWPS) 
   // are used up by one L2.  The next item's half tile and this item's chunks of the reference are requested before
   // the forward FFT: the memory latency (most of a one-shot workgroup's life: of its 56 kcycles, 20 went to waiting
   // for F and 10 for G) runs under the FFTs.
+  // The staging of an item's half tile sits at the END of the item before it, behind that item's stores: there the
+  // compiler knows how many younger operations follow the prefetch (vmcnt counts in order) and waits for the loads
+  // alone.  At the top of the loop it merged the loop's entry with its back edge and waited for everything: every
+  // item then began by draining the stores of the one before (~60 of 570 us per 64 frames of 2048^2).
   const int b = xcd_remap(blockIdx.x, gridDim.x);
   h8 fa[Cg::NL4];
-  if (b < nitems) load_half_tile<N>(F + (size_t)(b / ntiles) * F_stride, Wp, (b % ntiles) * Cg::TC, tid0, fa);
+  if (b < nitems) {
+    load_half_tile<N>(F + (size_t)(b / ntiles) * F_stride, Wp, (b % ntiles) * Cg::TC, tid0, fa);
+    stage_half_tile<N>(lds_c, (b % ntiles) * Cg::TC, nvalid, tid0, fa);
+  }
   for (int item = b; item < nitems; item += gridDim.x) {
     const int f = item / ntiles, tile = item - f * ntiles, v0 = tile * Cg::TC;
     // the thread index is made opaque per item: the LDS offsets of all passes depend on nothing else, and hoisted
@@ -707,12 +734,10 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, FftGeom<N>::CWPS) 
     int tid = tid0;
     asm volatile("" : "+v"(tid));
     const int c = tid / Cg::CNT, j = tid % Cg::CNT;
-    stage_half_tile<N>(lds_c, v0, nvalid, tid, fa);
-    __syncthreads();
-    {
-      const int nx = item + gridDim.x;
-      if (nx < nitems) load_half_tile<N>(F + (size_t)(nx / ntiles) * F_stride, Wp, (nx % ntiles) * Cg::TC, tid, fa);
-    }
+    __syncthreads();   // the tile is staged
+    const int nx = item + gridDim.x;
+    const int nv0 = nx < nitems ? (nx % ntiles) * Cg::TC : 0;
+    if (nx < nitems) load_half_tile<N>(F + (size_t)(nx / ntiles) * F_stride, Wp, nv0, tid, fa);
     // the reference's chunks: contiguous 16 bytes per lane, served by L2 / the Infinity Cache (every frame re-reads them)
     const int gf = G_stride ? f : 0;
     const h2* Gt = G + (size_t)gf * G_stride + (size_t)v0 * N;
@@ -726,6 +751,7 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, FftGeom<N>::CWPS) 
     fft_publish<Cg::CNT>();
     store_float_tile<N>(lds_c, Q + (size_t)f * Q_stride, Wp, v0, tid);
     __syncthreads();   // the tile is free for the next item
+    if (nx < nitems) stage_half_tile<N>(lds_c, nv0, nvalid, tid, fa);
   }
 }
 
