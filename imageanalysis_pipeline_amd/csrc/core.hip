@@ -37,7 +37,7 @@ hipEvent_t take_event() {
   return e;
 }
 const char* const k_names[K_COUNT] = {"smo_march_kernel", "smo_generic_kernel", "median_kernel", "sub_half_kernel",
-                                      "rows_r2c_kernel", "cols_kernel", "rows_c2r_argmax_kernel",
+                                      "rows_r2c16_kernel", "cols_xpower_kernel", "rows_c2r_argmax_kernel",
                                       "coarse_finish_kernel", "upsample_partial_kernel", "upsample_finish_kernel",
                                       "apply_shift_kernel", "measure_kernel", "measure_finalize_kernel", "mip_kernel",
                                       "accum_planes_kernel", "gauss_kernels", "roi_kernels", "max_u16_kernel", "other"};

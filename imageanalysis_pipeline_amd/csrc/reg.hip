@@ -380,6 +380,45 @@ __device__ __forceinline__ h2 to_h2(cf v) { return __builtin_convertvector(v, h2
 __device__ __forceinline__ cf from_h2(h2 v) { return __builtin_convertvector(v, cf); }
 template <int N> constexpr float fs16() { return 0.5f / (float)N; }
 
+// Storage of the spectra F and G: half pairs, or float pairs (F32) for FFT windows below 256 points on a side.
+// There few coefficients average the rounding of half spectra (relative 2^-12 each) and a correlation peak between
+// two different channels can be flat; such planes are small, so their spectra cost nothing as floats.  (The 0.02 px
+// misses of the randomised channel-shift run that round 2 put down to this rounding were the Nyquist row's factor in
+// the refinement, see up_row_sum; with both changes 1500 randomised planes stay within 0.01 px, most within 1e-5.)
+// Both forms move in pieces of four values: P4.
+template <bool F32> struct Sp;
+template <> struct Sp<false> {
+  typedef h2 E;
+  typedef h8 P4;
+  static __device__ __forceinline__ P4 pack(cf a, cf b, cf c, cf d) {
+    const h2 h0 = to_h2(a), h1 = to_h2(b), h2_ = to_h2(c), h3 = to_h2(d);
+    return (h8){h0.x, h0.y, h1.x, h1.y, h2_.x, h2_.y, h3.x, h3.y};
+  }
+  static __device__ __forceinline__ cf get(const P4& v, int i) { return from_h2((h2){v[2 * i], v[2 * i + 1]}); }
+  static __device__ __forceinline__ P4 load(const E* p) { return *reinterpret_cast<const P4*>(p); }
+  static __device__ __forceinline__ P4 load_nt(const E* p) { return __builtin_nontemporal_load(reinterpret_cast<const P4*>(p)); }
+  static __device__ __forceinline__ void store(E* p, const P4& v) { *reinterpret_cast<P4*>(p) = v; }
+};
+template <> struct Sp<true> {
+  typedef cf E;
+  struct P4 { float4 lo, hi; };
+  static __device__ __forceinline__ P4 pack(cf a, cf b, cf c, cf d) {
+    return P4{make_float4(a.x, a.y, b.x, b.y), make_float4(c.x, c.y, d.x, d.y)};
+  }
+  static __device__ __forceinline__ cf get(const P4& v, int i) {
+    const float4& q = i < 2 ? v.lo : v.hi;
+    return (i & 1) ? mkc(q.z, q.w) : mkc(q.x, q.y);
+  }
+  static __device__ __forceinline__ P4 load(const E* p) {
+    return P4{reinterpret_cast<const float4*>(p)[0], reinterpret_cast<const float4*>(p)[1]};
+  }
+  static __device__ __forceinline__ P4 load_nt(const E* p) { return load(p); }
+  static __device__ __forceinline__ void store(E* p, const P4& v) {
+    reinterpret_cast<float4*>(p)[0] = v.lo;
+    reinterpret_cast<float4*>(p)[1] = v.hi;
+  }
+};
+
 // two real rows per complex transform: Fa[k] = (Z[k] + conj Z[N-k]) / 2, Fb[k] = (Z[k] - conj Z[N-k]) / 2i
 template <int N>
 __device__ __forceinline__ void split_rows(const cf* sp, int k, cf& fa, cf& fb) {
@@ -442,9 +481,9 @@ struct R16Geom {
   static constexpr int KSTEP = NTH / NQ;                 // = 2 NT = N / 4: two rounds cover the bins below Nyquist
   static_assert(ROWS % 8 == 0 && NTH % (LG * NQ) == 0 && KSTEP * 2 == N / 2, "row blocks, lane groups, rounds");
 };
-template <int N, bool vec>
+template <int N, bool vec, bool F32>
 __global__ __launch_bounds__(R16Geom<N>::NTH, 8) void rows_r2c16_kernel(
-    const uint16_t* __restrict__ src, long long plane_stride, int srcX, int oy, int ox, h2* __restrict__ F,
+    const uint16_t* __restrict__ src, long long plane_stride, int srcX, int oy, int ox, typename Sp<F32>::E* __restrict__ F,
     long long F_stride, int Wp, const cf* __restrict__ tw, const int* __restrict__ sub2, long long sub_stride) {
   using Gm = FftGeom<N>;
   using Rg = R16Geom<N>;
@@ -488,10 +527,11 @@ __global__ __launch_bounds__(R16Geom<N>::NTH, 8) void rows_r2c16_kernel(
     cf f0, f1, f2, f3;
     split_rows<N>(sa, k, f0, f1);
     split_rows<N>(sb, k, f2, f3);
-    const h2 h0 = to_h2(f0), h1 = to_h2(f1), h2_ = to_h2(f2), h3 = to_h2(f3);
-    return (h8){h0.x, h0.y, h1.x, h1.y, h2_.x, h2_.y, h3.x, h3.y};
+    return Sp<F32>::pack(f0, f1, f2, f3);
   };
-  h2* Fo = F + (size_t)blockIdx.y * F_stride;
+  typedef typename Sp<F32>::E FE;
+  typedef typename Sp<F32>::P4 P4;
+  FE* Fo = F + (size_t)blockIdx.y * F_stride;
   u16x8 qa, qb;
   if (vec) fetch(0, qa, qb);
   stage(0, qa, qb);
@@ -501,25 +541,25 @@ __global__ __launch_bounds__(R16Geom<N>::NTH, 8) void rows_r2c16_kernel(
   fft_publish<Gm::NT>();   // the quads are read across the transforms' own thread groups
   if constexpr (Rg::STEPS == 1) {
     const int y0 = r0 + 4 * q;
-    *reinterpret_cast<h8*>(Fo + f_at(y0, k0, Wp)) = quad(k0);
-    *reinterpret_cast<h8*>(Fo + f_at(y0, k0 + Rg::KSTEP, Wp)) = quad(k0 + Rg::KSTEP);
-    if (k0 == 0) *reinterpret_cast<h8*>(Fo + f_at(y0, N / 2, Wp)) = quad(N / 2);
+    Sp<F32>::store(Fo + f_at(y0, k0, Wp), quad(k0));
+    Sp<F32>::store(Fo + f_at(y0, k0 + Rg::KSTEP, Wp), quad(k0 + Rg::KSTEP));
+    if (k0 == 0) Sp<F32>::store(Fo + f_at(y0, N / 2, Wp), quad(N / 2));
   } else {
     static_assert(Rg::STEPS == 1 || Rg::NQ == 1, "two steps: one quad per step");
-    const h8 a0 = quad(k0), a1 = quad(k0 + Rg::KSTEP);
-    h2* o = Fo + f_at(r0, k0, Wp);          // rows r0 .. r0 + 3 of column k0, rows r0 + 4 .. + 7 behind them
-    if (k0 == 0) *reinterpret_cast<h8*>(o + (size_t)(N / 2) * 8) = quad(N / 2);   // (the Nyquist column: half lines)
+    const P4 a0 = quad(k0), a1 = quad(k0 + Rg::KSTEP);
+    FE* o = Fo + f_at(r0, k0, Wp);          // rows r0 .. r0 + 3 of column k0, rows r0 + 4 .. + 7 behind them
+    if (k0 == 0) Sp<F32>::store(o + (size_t)(N / 2) * 8, quad(N / 2));   // (the Nyquist column: half lines)
     __syncthreads();   // the first step's spectra are in registers
     stage(1, qa, qb);
     __syncthreads();
     asm volatile("" : "+v"(j));   // the second transform works out its LDS offsets anew instead of holding the first one's
     fft_lds<N, -1>(s, j, tw);
     fft_publish<Gm::NT>();
-    *reinterpret_cast<h8*>(o) = a0;
-    *reinterpret_cast<h8*>(o + 4) = quad(k0);
-    *reinterpret_cast<h8*>(o + (size_t)Rg::KSTEP * 8) = a1;
-    *reinterpret_cast<h8*>(o + (size_t)Rg::KSTEP * 8 + 4) = quad(k0 + Rg::KSTEP);
-    if (k0 == 0) *reinterpret_cast<h8*>(o + (size_t)(N / 2) * 8 + 4) = quad(N / 2);
+    Sp<F32>::store(o, a0);
+    Sp<F32>::store(o + 4, quad(k0));
+    Sp<F32>::store(o + (size_t)Rg::KSTEP * 8, a1);
+    Sp<F32>::store(o + (size_t)Rg::KSTEP * 8 + 4, quad(k0 + Rg::KSTEP));
+    if (k0 == 0) Sp<F32>::store(o + (size_t)(N / 2) * 8 + 4, quad(N / 2));
   }
 }
 
@@ -556,18 +596,20 @@ __device__ __forceinline__ void stage_twiddles(cf* tw_s, const cf* __restrict__ 
 // Half tile of the row-interleaved spectrum F -> registers: 16-byte chunks of 4 rows of one column.  The tile's
 // share of an 8-row block is TC * 2 contiguous chunks (column c, rows 0..3 or 4..7 of the block): a thread owns the
 // chunks idx = tid + m * NTH, m < NL4, of the tile in that order, a wave's load is a run of whole lines.
-template <int N>
-__device__ __forceinline__ void load_half_tile(const h2* __restrict__ Ff, int Wp, int v0, int tid, h8 (&w)[ColGeom<N>::NL4]) {
+template <int N, bool F32>
+__device__ __forceinline__ void load_half_tile(const typename Sp<F32>::E* __restrict__ Ff, int Wp, int v0, int tid,
+                                               typename Sp<F32>::P4 (&w)[ColGeom<N>::NL4]) {
   using Cg = ColGeom<N>;
 #pragma unroll
   for (int m = 0; m < Cg::NL4; ++m) {
     const int idx = tid + m * Cg::NTH;
     // (streaming: a line of F is used once, by this tile)
-    w[m] = __builtin_nontemporal_load(reinterpret_cast<const h8*>(Ff + ((size_t)(idx / (2 * Cg::TC)) * Wp + v0) * 8 + (idx % (2 * Cg::TC)) * 4));
+    w[m] = Sp<F32>::load_nt(Ff + ((size_t)(idx / (2 * Cg::TC)) * Wp + v0) * 8 + (idx % (2 * Cg::TC)) * 4);
   }
 }
-template <int N>
-__device__ __forceinline__ void stage_half_tile(cf* lds, int v0, int nvalid, int tid, const h8 (&w)[ColGeom<N>::NL4]) {
+template <int N, bool F32>
+__device__ __forceinline__ void stage_half_tile(cf* lds, int v0, int nvalid, int tid,
+                                                const typename Sp<F32>::P4 (&w)[ColGeom<N>::NL4]) {
   using Cg = ColGeom<N>;
 #pragma unroll
   for (int m = 0; m < Cg::NL4; ++m) {
@@ -577,11 +619,11 @@ __device__ __forceinline__ void stage_half_tile(cf* lds, int v0, int nvalid, int
     if (v0 + Cg::TC <= nvalid) {   // (uniform) every tile but the last
 #pragma unroll
       for (int h = 0; h < 4; ++h)   // (16 points per thread: 4 | u0, the four rows share a pad group and are contiguous)
-        d[padi<Cg::CE>(u0 + h)] = from_h2((h2){w[m][2 * h], w[m][2 * h + 1]});
+        d[padi<Cg::CE>(u0 + h)] = Sp<F32>::get(w[m], h);
     } else {
       const bool ok = v0 + c < nvalid;   // padding columns hold whatever the workspace held
 #pragma unroll
-      for (int h = 0; h < 4; ++h) d[padi<Cg::CE>(u0 + h)] = ok ? from_h2((h2){w[m][2 * h], w[m][2 * h + 1]}) : mkc(0.f, 0.f);
+      for (int h = 0; h < 4; ++h) d[padi<Cg::CE>(u0 + h)] = ok ? Sp<F32>::get(w[m], h) : mkc(0.f, 0.f);
     }
   }
 }
@@ -637,9 +679,9 @@ __device__ __forceinline__ void column_correlate(cf* s, int j, const cf* __restr
   fft_inv_regs<N, Cg::CE>(s, j, tw_s, x);
 }
 
-template <int N>
+template <int N, bool F32>
 __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, FftGeom<N>::CWPS) void cols_ref_kernel(
-    const cf* __restrict__ F, long long F_stride, h2* __restrict__ G, long long G_stride, float* __restrict__ gscale,
+    const cf* __restrict__ F, long long F_stride, typename Sp<F32>::E* __restrict__ G, long long G_stride, float* __restrict__ gscale,
     int gs_stride, int Wp, int nvalid, const cf* __restrict__ tw) {
   using Cg = ColGeom<N>;
   extern __shared__ cf lds_c[];
@@ -683,28 +725,22 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, FftGeom<N>::CWPS) 
   for (int k = 0; k < (Cg::NTH + 63) / 64; ++k) mx = fmaxf(mx, wmax[k]);
   int ex = 0;
   float sc = 1.f;
-  if (mx > 0.f && mx < INFINITY) {
+  if (!F32 && mx > 0.f && mx < INFINITY) {   // (float spectra are stored as they are)
     (void)frexpf(mx, &ex);          // mx = m 2^ex, m in [0.5, 1)
     sc = ldexpf(1.f, 15 - ex);
   }
   if (tid == 0) gscale[(size_t)frame * gs_stride + tile] = 1.0f / sc;
-  h2* Gt = G + (size_t)frame * G_stride + (size_t)v0 * N;
+  typename Sp<F32>::E* Gt = G + (size_t)frame * G_stride + (size_t)v0 * N;
+  const cf s2 = {sc, sc};
 #pragma unroll
-  for (int q = 0; q < Cg::NLG; ++q) {
-    h8 o;
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      const h2 t = to_h2(v[4 * q + h] * (cf){sc, sc});
-      o[2 * h] = t.x;
-      o[2 * h + 1] = t.y;
-    }
-    *reinterpret_cast<h8*>(Gt + ((size_t)q * Cg::NTH + tid) * 4) = o;
-  }
+  for (int q = 0; q < Cg::NLG; ++q)
+    Sp<F32>::store(Gt + ((size_t)q * Cg::NTH + tid) * 4,
+                   Sp<F32>::pack(v[4 * q] * s2, v[4 * q + 1] * s2, v[4 * q + 2] * s2, v[4 * q + 3] * s2));
 }
 
-template <int N>
+template <int N, bool F32>
 __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, FftGeom<N>::CWPS) void cols_xpower_kernel(
-    const h2* __restrict__ F, long long F_stride, const h2* __restrict__ G, long long G_stride,
+    const typename Sp<F32>::E* __restrict__ F, long long F_stride, const typename Sp<F32>::E* __restrict__ G, long long G_stride,
     const float* __restrict__ gscale, int gs_stride, cf* __restrict__ Q, long long Q_stride, int Wp, int nvalid,
     const cf* __restrict__ tw, int normalize, float scale, int ntiles, int nitems) {
   using Cg = ColGeom<N>;
@@ -722,10 +758,11 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, FftGeom<N>::CWPS) 
   // alone.  At the top of the loop it merged the loop's entry with its back edge and waited for everything: every
   // item then began by draining the stores of the one before (~60 of 570 us per 64 frames of 2048^2).
   const int b = xcd_remap(blockIdx.x, gridDim.x);
-  h8 fa[Cg::NL4];
+  typedef typename Sp<F32>::P4 P4;
+  P4 fa[Cg::NL4];
   if (b < nitems) {
-    load_half_tile<N>(F + (size_t)(b / ntiles) * F_stride, Wp, (b % ntiles) * Cg::TC, tid0, fa);
-    stage_half_tile<N>(lds_c, (b % ntiles) * Cg::TC, nvalid, tid0, fa);
+    load_half_tile<N, F32>(F + (size_t)(b / ntiles) * F_stride, Wp, (b % ntiles) * Cg::TC, tid0, fa);
+    stage_half_tile<N, F32>(lds_c, (b % ntiles) * Cg::TC, nvalid, tid0, fa);
   }
   for (int item = b; item < nitems; item += gridDim.x) {
     const int f = item / ntiles, tile = item - f * ntiles, v0 = tile * Cg::TC;
@@ -737,27 +774,26 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, FftGeom<N>::CWPS) 
     __syncthreads();   // the tile is staged
     const int nx = item + gridDim.x;
     const int nv0 = nx < nitems ? (nx % ntiles) * Cg::TC : 0;
-    if (nx < nitems) load_half_tile<N>(F + (size_t)(nx / ntiles) * F_stride, Wp, nv0, tid, fa);
+    if (nx < nitems) load_half_tile<N, F32>(F + (size_t)(nx / ntiles) * F_stride, Wp, nv0, tid, fa);
     // the reference's chunks: contiguous 16 bytes per lane, served by L2 / the Infinity Cache (every frame re-reads them)
     const int gf = G_stride ? f : 0;
-    const h2* Gt = G + (size_t)gf * G_stride + (size_t)v0 * N;
+    const typename Sp<F32>::E* Gt = G + (size_t)gf * G_stride + (size_t)v0 * N;
     const float sc = scale * gscale[(size_t)gf * gs_stride + tile];
-    h8 g[Cg::NLG];
+    P4 g[Cg::NLG];
 #pragma unroll
-    for (int q = 0; q < Cg::NLG; ++q) g[q] = *reinterpret_cast<const h8*>(Gt + ((size_t)q * Cg::NTH + tid) * 4);
-    column_correlate<N>(lds_c + c * Cg::CS, j, tw_s,
-                        [&](int m) { return from_h2((h2){g[m >> 2][2 * (m & 3)], g[m >> 2][2 * (m & 3) + 1]}); }, sc,
+    for (int q = 0; q < Cg::NLG; ++q) g[q] = Sp<F32>::load(Gt + ((size_t)q * Cg::NTH + tid) * 4);
+    column_correlate<N>(lds_c + c * Cg::CS, j, tw_s, [&](int m) { return Sp<F32>::get(g[m >> 2], m & 3); }, sc,
                         normalize, v0 + c == 0);
     fft_publish<Cg::CNT>();
     store_float_tile<N>(lds_c, Q + (size_t)f * Q_stride, Wp, v0, tid);
     __syncthreads();   // the tile is free for the next item
-    if (nx < nitems) stage_half_tile<N>(lds_c, nv0, nvalid, tid, fa);
+    if (nx < nitems) stage_half_tile<N, F32>(lds_c, nv0, nvalid, tid, fa);
   }
 }
 
-template <int N>
+template <int N, bool F32>
 __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 2) void cols_fused_kernel(
-    const h2* __restrict__ F, long long F_stride, const h2* __restrict__ Gref, long long G_stride,
+    const typename Sp<F32>::E* __restrict__ F, long long F_stride, const typename Sp<F32>::E* __restrict__ Gref, long long G_stride,
     cf* __restrict__ Q, long long Q_stride, int Wp, int nvalid, const cf* __restrict__ tw, int normalize, float scale) {
   using Cg = ColGeom<N>;
   extern __shared__ cf lds_c[];
@@ -769,11 +805,11 @@ __global__ __launch_bounds__(FftGeom<N>::TC* FftGeom<N>::CNT, 2) void cols_fused
   __shared__ cf tw_s[FftGeom<N>::TWL];
   stage_twiddles<N>(tw_s, tw, tid);
   {
-    h8 w[Cg::NL4];
-    load_half_tile<N>(F + (size_t)frame * F_stride, Wp, v0, tid, w);
-    stage_half_tile<N>(lds_c, v0, nvalid, tid, w);
-    load_half_tile<N>(Gref + (size_t)frame * G_stride, Wp, v0, tid, w);
-    stage_half_tile<N>(lds_g, v0, nvalid, tid, w);
+    typename Sp<F32>::P4 w[Cg::NL4];
+    load_half_tile<N, F32>(F + (size_t)frame * F_stride, Wp, v0, tid, w);
+    stage_half_tile<N, F32>(lds_c, v0, nvalid, tid, w);
+    load_half_tile<N, F32>(Gref + (size_t)frame * G_stride, Wp, v0, tid, w);
+    stage_half_tile<N, F32>(lds_g, v0, nvalid, tid, w);
   }
   __syncthreads();
   // the reference's column transform ends in LDS; thread (c, j) then reads back its own column's values only
@@ -910,7 +946,8 @@ __global__ __launch_bounds__(256) void coarse_finish_kernel(const float* __restr
 //   K(t) = 1/Py sum_fu exp(2 pi i fu t / Py) = Ks(t) + exp(-i pi t) / Py,
 //   Ks(t) = sin(pi t (Py-1)/Py) / (Py sin(pi t / Py))          (real: the frequencies |fu| < Py/2)
 // so a row contributes 15 real weights Ks(y'_j - y) and the term of the Nyquist row,
-// exp(-i pi y'_j) * sum_y (-1)^y Q[y][v] / Py, rides as a 16th real weight.  Along x the +-m symmetry
+// cos(pi y'_j) * sum_y (-1)^y Q[y][v] / Py (the cosine, not the exponential: see up_row_sum), rides as a 16th real
+// weight.  Along x the +-m symmetry
 // halves the work: ex[v][7 +- m] = base_v (a_m +- i b_m), a_m + i b_m = exp(2 pi i fv 0.1 m / Px).
 constexpr int UP_N = 15;       // grid points per axis: offsets -0.7 .. 0.7
 constexpr int UP_HALF = 7;
@@ -960,20 +997,25 @@ __device__ __forceinline__ double row_weight(double sa, double ca, bool odd, con
 //   U[7][7] = V77,  U[j][7] = Vj7 - V77,  U[7][k] = V7k - V77,  U[j][k] = (Vjk - Vj7) - (V7k - V77)
 // and the finish kernel works on D[j][k] = Vjk - V77 = U[j][7] + U[7][k] + U[j][k] in double (V77 itself is not needed).
 //
-// T'[j] (j = 0..14) from the weighted row sums: acc[j] + e_j acc[15], e_j = exp(-i pi y'_j) (- exp(-i pi y'_7) for
-// j != 7), y'_j = sy + 0.1 (j - 7)
+// T'[j] (j = 0..14) from the weighted row sums: acc[j] + e_j acc[15], y'_j = sy + 0.1 (j - 7).  acc[15] is the
+// Nyquist row R[Py/2][v], whose frequency counts as -Py/2 (fftfreq's convention, the oracle's and skimage's).  Its
+// factor is e_j = cos(pi y'_j) (- cos(pi y'_7) for j != 7), NOT exp(-i pi y'_j): the refinement sums the half
+// spectrum v <= Px/2 and doubles, which stands for the pair (u, v), (-u, -v) -- but the Nyquist row is its own
+// mirror image, its pair is (Py/2, v), (Py/2, -v), both with the SAME factor exp(-i pi y'), and their sum is
+// exp(-i pi y') 2 Re(R E_v): the real part keeps the cosine only.  With the sine in, the grid carried an extra term
+// antisymmetric in the offset, proportional to the energy in that one row: nothing on 2048 rows, but on a 64-row
+// window of two different channels it moved one vertex in ~600 planes by 0.03 px (round 3; until then put down to
+// half-precision spectra).
 __device__ __forceinline__ v2f up_row_sum(int j, int sy, const v2f* acc) {
-  // cos, sin of pi m / 10, m = 0..7
+  // cos of pi m / 10, m = 0..7
   constexpr float C[8] = {1.f, 0.95105651629515357f, 0.80901699437494742f, 0.58778525229247313f,
                           0.30901699437494742f, 0.f, -0.30901699437494742f, -0.58778525229247313f};
-  constexpr float S[8] = {0.f, 0.30901699437494742f, 0.58778525229247313f, 0.80901699437494742f,
-                          0.95105651629515357f, 1.f, 0.95105651629515357f, 0.80901699437494742f};
   const int m = j >= UP_HALF ? j - UP_HALF : UP_HALF - j;
   const float sg = (sy & 1) ? -1.f : 1.f;
-  // exp(-i pi y') = (-1)^sy (cos - i sin)(pi (j-7)/10); off the centre row minus its value there, (-1)^sy
-  const float pc = sg * (m ? C[m] - 1.f : 1.f), ps = (j >= UP_HALF ? -sg : sg) * S[m];
+  // cos(pi y') = (-1)^sy cos(pi (j-7)/10); off the centre row minus its value there, (-1)^sy
+  const float pc = sg * (m ? C[m] - 1.f : 1.f);
   const v2f n = acc[UP_N];
-  return (v2f){acc[j].x + (n.x * pc - n.y * ps), acc[j].y + (n.x * ps + n.y * pc)};
+  return (v2f){acc[j].x + n.x * pc, acc[j].y + n.y * pc};
 }
 
 // Row and column records of every frame of the batch (the coarse shift enters the row weights
@@ -1752,6 +1794,7 @@ struct RegPlan {
   int row_blocks;   // workgroups of the inverse row kernel per frame (= arg-max partials)
   int col_blocks;
   int ncg, nuc;     // upsample chunks: column groups x row chunks
+  int fb;           // bytes per value of the spectra F and G: 4 (half pairs), 8 (float pairs: windows below 256 points)
 };
 
 // row pairs per workgroup of the inverse row kernel (FftGeom<N>::RPQ)
@@ -1772,6 +1815,7 @@ static bool make_plan(int Y, int X, RegPlan& p) {
   p.ox = (X - p.Px) / 2;
   p.Wp = (p.Px / 2 + 1 + 15) / 16 * 16;
   p.spec = (size_t)p.Py * p.Wp;
+  p.fb = (p.Py < 256 || p.Px < 256) ? 8 : 4;
   p.row_blocks = p.Py / 2 / geom_rows_RPQ(p.Px);
   p.col_blocks = p.Wp / geom_TC(p.Py);
   p.ncg = (p.Px / 2 + 511) / 512;
@@ -1781,9 +1825,9 @@ static bool make_plan(int Y, int X, RegPlan& p) {
 
 struct RegWs {
   cf *tw_x, *tw_y;
-  h2* refspec;     // the reference's full spectrum: half pairs, tile-major chunks (cols_ref_kernel)
+  char* refspec;   // the reference's full spectrum: p.fb bytes per value, in the column kernel's order (cols_ref_kernel)
   float* gscale;   // ... and the factor per tile that undoes its scale
-  h2* F;           // row spectra of the batch's moving planes, half pairs
+  char* F;         // row spectra of the batch's moving planes, p.fb bytes per value
   cf* Q;           // float: the batch's Q[y][v]; its slots also take the float row spectra on their way to cols_ref
   float* pval;
   int* pidx;
@@ -1799,11 +1843,11 @@ struct RegWs {
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 static size_t reg_fixed_bytes(const RegPlan& p) {
-  return align256(4096 * 8) * 2 + align256(p.spec * 4) + align256((size_t)p.col_blocks * 4) +
+  return align256(4096 * 8) * 2 + align256(p.spec * p.fb) + align256((size_t)p.col_blocks * 4) +
          align256((size_t)p.Y * p.X * 2) + align256((size_t)p.Y * p.X * 4) + 1024;
 }
 static size_t reg_frame_bytes(const RegPlan& p, int Z) {
-  size_t b = align256(p.spec * 4) + align256(p.spec * 8) + 2 * align256((size_t)p.row_blocks * 4) + 256 +
+  size_t b = align256(p.spec * p.fb) + align256(p.spec * 8) + 2 * align256((size_t)p.row_blocks * 4) + 256 +
              align256((size_t)p.ncg * p.nuc * UP_NV * 4) + align256((size_t)p.Py * UP_YS * 4) +
              align256((size_t)p.Wp * UP_XS * 4) + align256((size_t)((p.Py + 255) / 256) * UP_NQ * 4);
   if (Z > 1) b += align256((size_t)p.Y * p.X * 2);
@@ -1824,11 +1868,11 @@ static bool carve(void* ws, size_t bytes, const RegPlan& p, int Z, RegWs& w) {
   };
   w.tw_x = (cf*)take(4096 * 8);
   w.tw_y = (cf*)take(4096 * 8);
-  w.refspec = (h2*)take(p.spec * 4);
+  w.refspec = take(p.spec * p.fb);
   w.gscale = (float*)take((size_t)p.col_blocks * 4);
   w.mip_ref = (uint16_t*)take((size_t)p.Y * p.X * 2);
   w.sum = (uint32_t*)take((size_t)p.Y * p.X * 4);
-  w.F = (h2*)take((size_t)batch * align256(p.spec * 4));
+  w.F = take((size_t)batch * align256(p.spec * p.fb));
   w.Q = (cf*)take((size_t)batch * align256(p.spec * 8));
   w.pval = (float*)take((size_t)batch * p.row_blocks * 4);
   w.pidx = (int*)take((size_t)batch * p.row_blocks * 4);
@@ -1868,6 +1912,13 @@ struct PlaneSub {
 
 // half16: the row spectra go out as packed half pairs (moving planes; F_stride in half pairs), else as float
 // (the reference plane on its way to cols_ref_kernel; F_stride in float pairs)
+#define IAP_R2C16(VEC, F32)                                                                                          \
+  do {                                                                                                               \
+    IAP_HIP(allow_lds((rows_r2c16_kernel<N, VEC, F32>), lds));                                                       \
+    hipLaunchKernelGGL((rows_r2c16_kernel<N, VEC, F32>), dim3(p.Py / Rg::ROWS, n), dim3(Rg::NTH), lds, st,           \
+                       (const uint16_t*)src, plane_stride, p.X, p.oy, p.ox, (typename Sp<F32>::E*)F, F_stride, p.Wp, \
+                       tw_x, sub.sub2, sub.stride);                                                                  \
+  } while (0)
 static int launch_rows_r2c(const RegPlan& p, const void* src, int kind, long long plane_stride, float in_scale,
                            void* F, long long F_stride, bool half16, int n, const cf* tw_x, hipStream_t st,
                            PlaneSub sub = {}) {
@@ -1880,14 +1931,10 @@ static int launch_rows_r2c(const RegPlan& p, const void* src, int kind, long lon
       using Rg = R16Geom<N>;
       if (kind != 0 || in_scale != 1.0f) return IAP_E_ARG;   // the moving planes are u16
       const size_t lds = (size_t)Rg::PS * Gm::PADN * sizeof(cf);
-      if (vec) {
-        IAP_HIP(allow_lds((rows_r2c16_kernel<N, true>), lds));
-        hipLaunchKernelGGL((rows_r2c16_kernel<N, true>), dim3(p.Py / Rg::ROWS, n), dim3(Rg::NTH), lds, st, (const uint16_t*)src,
-                           plane_stride, p.X, p.oy, p.ox, (h2*)F, F_stride, p.Wp, tw_x, sub.sub2, sub.stride);
+      if (p.fb == 8) {
+        if (vec) IAP_R2C16(true, true); else IAP_R2C16(false, true);
       } else {
-        IAP_HIP(allow_lds((rows_r2c16_kernel<N, false>), lds));
-        hipLaunchKernelGGL((rows_r2c16_kernel<N, false>), dim3(p.Py / Rg::ROWS, n), dim3(Rg::NTH), lds, st, (const uint16_t*)src,
-                           plane_stride, p.X, p.oy, p.ox, (h2*)F, F_stride, p.Wp, tw_x, sub.sub2, sub.stride);
+        if (vec) IAP_R2C16(true, false); else IAP_R2C16(false, false);
       }
     } else {
       const size_t lds = (size_t)Gm::G * Gm::PADN * sizeof(cf);
@@ -1900,20 +1947,26 @@ static int launch_rows_r2c(const RegPlan& p, const void* src, int kind, long lon
   return IAP_OK;
 }
 
-static long long spec16_stride(const RegPlan& p) { return (long long)(align256(p.spec * 4) / 4); }   // half pairs
+static long long spec16_stride(const RegPlan& p) { return (long long)(align256(p.spec * p.fb) / p.fb); }   // values of F / G
 static long long spec32_stride(const RegPlan& p) { return (long long)(align256(p.spec * 8) / 8); }   // float pairs
 static int valid_tiles(const RegPlan& p) { return (p.Px / 2 + 1 + geom_TC(p.Py) - 1) / geom_TC(p.Py); }
 
 // n references: float row spectra F -> column FFT -> G (half pairs, tile-major chunks) + gscale per tile
-static int launch_cols_ref(const RegPlan& p, const cf* F, long long F_stride, h2* G, long long G_stride, float* gscale,
+static int launch_cols_ref(const RegPlan& p, const cf* F, long long F_stride, void* G, long long G_stride, float* gscale,
                            int n, const cf* tw_y, hipStream_t st) {
   IAP_FOR_N(p.Py, {
     using Gm = FftGeom<N>;
     size_t lds = (size_t)Gm::TC * Gm::CS * sizeof(cf);
-    IAP_HIP(allow_lds(cols_ref_kernel<N>, lds));
     ProfScope ps_(K_COLS, st);
-    hipLaunchKernelGGL(cols_ref_kernel<N>, dim3(valid_tiles(p), n), dim3(Gm::TC * Gm::CNT), lds, st, F, F_stride, G,
-                       G_stride, gscale, p.col_blocks, p.Wp, p.Px / 2 + 1, tw_y);
+    if (p.fb == 8) {
+      IAP_HIP(allow_lds((cols_ref_kernel<N, true>), lds));
+      hipLaunchKernelGGL((cols_ref_kernel<N, true>), dim3(valid_tiles(p), n), dim3(Gm::TC * Gm::CNT), lds, st, F, F_stride,
+                         (cf*)G, G_stride, gscale, p.col_blocks, p.Wp, p.Px / 2 + 1, tw_y);
+    } else {
+      IAP_HIP(allow_lds((cols_ref_kernel<N, false>), lds));
+      hipLaunchKernelGGL((cols_ref_kernel<N, false>), dim3(valid_tiles(p), n), dim3(Gm::TC * Gm::CNT), lds, st, F, F_stride,
+                         (h2*)G, G_stride, gscale, p.col_blocks, p.Wp, p.Px / 2 + 1, tw_y);
+    }
   });
   IAP_LAUNCH_CHECK();
   return IAP_OK;
@@ -1922,50 +1975,62 @@ static int launch_cols_ref(const RegPlan& p, const cf* F, long long F_stride, h2
 // n moving frames (half row spectra F) against G (one for all: G_stride 0, or one per frame) -> Q (float)
 // workgroups of cols_xpower_kernel<N> that are resident at once on this device (0 on error); one cache per plane
 // size and device, the queries are slow
-template <int N>
+template <int N, bool F32>
 static int cols_resident(int threads, size_t lds) {
   static std::atomic<int> known[64];
   int per_cu = 0, dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 0;
   if (dev >= 0 && dev < 64 && known[dev].load() > 0) return known[dev].load();
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cols_xpower_kernel<N>, threads, lds) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cols_xpower_kernel<N, F32>, threads, lds) != hipSuccess) return 0;
   if (dev >= 0 && dev < 64) known[dev].store(per_cu * cus);
   return per_cu * cus;
 }
 
-static int launch_cols_xpower(const RegPlan& p, const h2* F, const h2* G, long long G_stride, const float* gscale,
+#define IAP_XPOWER(F32)                                                                                                \
+  do {                                                                                                                 \
+    typedef typename Sp<F32>::E FE;                                                                                    \
+    IAP_HIP(allow_lds((cols_xpower_kernel<N, F32>), lds));                                                             \
+    const int resident = cols_resident<N, F32>(Gm::TC * Gm::CNT, lds);                                                 \
+    if (resident < 1) return (int)hipErrorUnknown;                                                                     \
+    hipLaunchKernelGGL((cols_xpower_kernel<N, F32>), dim3((unsigned)std::min<long long>(items, resident)),             \
+                       dim3(Gm::TC * Gm::CNT), lds, st, (const FE*)F, spec16_stride(p), (const FE*)G, G_stride, gscale, \
+                       p.col_blocks, Q, spec32_stride(p), p.Wp, p.Px / 2 + 1, tw_y, normalize, scale, valid_tiles(p),  \
+                       (int)items);                                                                                    \
+  } while (0)
+static int launch_cols_xpower(const RegPlan& p, const void* F, const void* G, long long G_stride, const float* gscale,
                               cf* Q, int n, const cf* tw_y, int normalize, hipStream_t st) {
   // F holds F_true * 0.5 / Px (fs16), G holds G_true / gscale: P = G conj(F) / (Py Px) needs 2 Px / (Py Px)
   const float scale = 2.0f / (float)p.Py;
   IAP_FOR_N(p.Py, {
     using Gm = FftGeom<N>;
     size_t lds = (size_t)Gm::TC * Gm::CS * sizeof(cf);
-    IAP_HIP(allow_lds(cols_xpower_kernel<N>, lds));
     ProfScope ps_(K_COLS, st);
     const long long items = (long long)valid_tiles(p) * n;
     if (items > 0x7fffffffLL) return IAP_E_UNSUPPORTED;
-    const int resident = cols_resident<N>(Gm::TC * Gm::CNT, lds);
-    if (resident < 1) return (int)hipErrorUnknown;
-    hipLaunchKernelGGL(cols_xpower_kernel<N>, dim3((unsigned)std::min<long long>(items, resident)), dim3(Gm::TC * Gm::CNT),
-                       lds, st, F, spec16_stride(p), G, G_stride, gscale, p.col_blocks, Q, spec32_stride(p), p.Wp,
-                       p.Px / 2 + 1, tw_y, normalize, scale, valid_tiles(p), (int)items);
+    if (p.fb == 8) IAP_XPOWER(true); else IAP_XPOWER(false);
   });
   IAP_LAUNCH_CHECK();
   return IAP_OK;
 }
 
 // n moving frames (half row spectra F) against half ROW spectra of their references (G_stride 0: one for all)
-static int launch_cols_fused(const RegPlan& p, const h2* F, const h2* Grows, long long G_stride, cf* Q, int n,
+static int launch_cols_fused(const RegPlan& p, const void* F, const void* Grows, long long G_stride, cf* Q, int n,
                              const cf* tw_y, int normalize, hipStream_t st) {
   const float scale = 4.0f * (float)p.Px / (float)p.Py;   // both factors carry fs16 = 0.5 / Px
   IAP_FOR_N(p.Py, {
     using Gm = FftGeom<N>;
     size_t lds = (size_t)Gm::TC * Gm::CS * sizeof(cf) * 2;
-    IAP_HIP(allow_lds(cols_fused_kernel<N>, lds));
     ProfScope ps_(K_COLS, st);
-    hipLaunchKernelGGL(cols_fused_kernel<N>, dim3(valid_tiles(p), n), dim3(Gm::TC * Gm::CNT), lds, st, F, spec16_stride(p),
-                       Grows, G_stride, Q, spec32_stride(p), p.Wp, p.Px / 2 + 1, tw_y, normalize, scale);
+    if (p.fb == 8) {
+      IAP_HIP(allow_lds((cols_fused_kernel<N, true>), lds));
+      hipLaunchKernelGGL((cols_fused_kernel<N, true>), dim3(valid_tiles(p), n), dim3(Gm::TC * Gm::CNT), lds, st, (const cf*)F,
+                         spec16_stride(p), (const cf*)Grows, G_stride, Q, spec32_stride(p), p.Wp, p.Px / 2 + 1, tw_y, normalize, scale);
+    } else {
+      IAP_HIP(allow_lds((cols_fused_kernel<N, false>), lds));
+      hipLaunchKernelGGL((cols_fused_kernel<N, false>), dim3(valid_tiles(p), n), dim3(Gm::TC * Gm::CNT), lds, st, (const h2*)F,
+                         spec16_stride(p), (const h2*)Grows, G_stride, Q, spec32_stride(p), p.Wp, p.Px / 2 + 1, tw_y, normalize, scale);
+    }
   });
   IAP_LAUNCH_CHECK();
   return IAP_OK;
@@ -2003,21 +2068,21 @@ static int reg_ref_spectrum(const RegPlan& p, RegWs& w, const void* ref, int kin
 // The reference of an estimate: w.refspec (default), one spectrum per frame (gref/gscale, channel-shift pairs), or
 // the half ROW spectrum of one reference plane (ref_rows: the serial 'previous' chain, cols_fused_kernel).
 struct RegRef {
-  const h2* gref = nullptr;
+  const void* gref = nullptr;
   long long g_stride = 0;
   const float* gscale = nullptr;
-  const h2* ref_rows = nullptr;
+  const void* ref_rows = nullptr;
 };
 
 // shifts for n moving planes (n <= w.batch)
 static int reg_estimate_batch(const RegPlan& p, RegWs& w, const uint16_t* mov, long long mov_stride, int n, int flags,
-                              double* shifts, hipStream_t st, RegRef ref = {}, const h2* rows = nullptr,
+                              double* shifts, hipStream_t st, RegRef ref = {}, const void* rows = nullptr,
                               PlaneSub msub = {}) {
   // rows != nullptr: the n row-pass spectra are already there (slots of w.F filled ahead of a serial loop)
   const long long fs = spec32_stride(p);
   const bool up = flags & IAP_REG_UPSAMPLE;
   const int normalize = (flags & IAP_REG_NORMALIZE) ? 1 : 0;
-  const h2* F16 = rows ? rows : w.F;
+  const void* F16 = rows ? rows : w.F;
   int rc = rows ? IAP_OK : launch_rows_r2c(p, mov, 0, mov_stride, 1.0f, w.F, spec16_stride(p), true, n, w.tw_x, st, msub);
   if (rc) return rc;
   if (ref.ref_rows) rc = launch_cols_fused(p, F16, ref.ref_rows, 0, w.Q, n, w.tw_y, normalize, st);
@@ -2181,7 +2246,7 @@ extern "C" int iap_reg_estimate_u16(const void* ref, int ref_kind, const uint16_
 // registration channel): the workspace is that of the plain estimate plus one reference spectrum per
 // frame of the batch.
 // one reference spectrum (half pairs) and its per-tile scales per frame of the batch
-static size_t pair_ref_bytes(const RegPlan& p) { return align256(p.spec * 4) + align256((size_t)p.col_blocks * 4); }
+static size_t pair_ref_bytes(const RegPlan& p) { return align256(p.spec * p.fb) + align256((size_t)p.col_blocks * 4); }
 
 extern "C" size_t iap_reg_pairs_ws_bytes(int Y, int X, int batch) {
   RegPlan p;
@@ -2201,14 +2266,14 @@ extern "C" int iap_reg_estimate_pairs_u16(const uint16_t* ref, int64_t ref_strid
   int rc = reg_check("iap_reg_estimate_pairs_u16", Y, X, p);
   if (rc) return rc;
   // split the workspace: per-frame reference spectra and their scales first, the plain estimate's layout in the rest
-  const size_t gs = align256(p.spec * 4), ss = align256((size_t)p.col_blocks * 4), per = reg_frame_bytes(p, 1) + gs + ss,
+  const size_t gs = align256(p.spec * p.fb), ss = align256((size_t)p.col_blocks * 4), per = reg_frame_bytes(p, 1) + gs + ss,
                fixed = reg_fixed_bytes(p);
   IAP_REQUIRE(ws_bytes >= fixed + per + 512, IAP_E_WS, "iap_reg_estimate_pairs_u16: workspace of %zu bytes, need %zu",
               ws_bytes, iap_reg_pairs_ws_bytes(Y, X, 1));
   int batch = (int)((ws_bytes - fixed - 512) / per);
   if (batch > 4096) batch = 4096;
   char* base = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-  h2* gref = (h2*)base;
+  char* gref = base;
   float* gscale = (float*)(base + (size_t)batch * gs);
   RegWs w;
   IAP_REQUIRE(carve(base + (size_t)batch * (gs + ss), fixed + (size_t)batch * reg_frame_bytes(p, 1) + 256, p, 1, w) && w.batch >= 1,
@@ -2219,7 +2284,7 @@ extern "C" int iap_reg_estimate_pairs_u16(const uint16_t* ref, int64_t ref_strid
   if (rc) return rc;
   RegRef rr;
   rr.gref = gref;
-  rr.g_stride = (long long)(gs / 4);
+  rr.g_stride = (long long)(gs / p.fb);
   rr.gscale = gscale;
   for (int64_t f0 = 0; f0 < n; f0 += w.batch) {
     const int nb = (int)(n - f0 < w.batch ? n - f0 : w.batch);
@@ -2319,7 +2384,7 @@ static int im_reg_impl(const uint16_t* in, uint16_t* out, int64_t T, int C, int 
       rc = mov_planes(in, f0, nb, mp, ms, msub);
       if (rc) return rc;
       if (ahead) {
-        rc = launch_rows_r2c(p, mp, 0, ms, 1.0f, w.F + fs, fs, true, nb, w.tw_x, st, msub);
+        rc = launch_rows_r2c(p, mp, 0, ms, 1.0f, w.F + fs * p.fb, fs, true, nb, w.tw_x, st, msub);
         if (rc) return rc;
       }
       for (int k = 0; k < nb; ++k) {
@@ -2337,7 +2402,7 @@ static int im_reg_impl(const uint16_t* in, uint16_t* out, int64_t T, int C, int 
           if (rc) return rc;
           RegRef rr;
           rr.ref_rows = w.F;
-          rc = reg_estimate_batch(p, w, mp, ms, 1, flags, shifts_out + 2 * f, st, rr, w.F + (size_t)(k + 1) * fs);
+          rc = reg_estimate_batch(p, w, mp, ms, 1, flags, shifts_out + 2 * f, st, rr, w.F + (size_t)(k + 1) * fs * p.fb);
         } else {   // a one-frame workspace: the same arithmetic, the reference's row spectrum in w.refspec's place
           rc = launch_rows_r2c(p, refp, 0, 0, 1.0f, w.refspec, 0, true, 1, w.tw_x, st);
           if (rc) return rc;

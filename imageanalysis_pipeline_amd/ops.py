@@ -501,6 +501,12 @@ def hot_path(stack: torch.Tensor, labels: torch.Tensor, threshold: float, reg_ch
                        out=scratch.view(t, 1, 1, y, x))
     del scratch
     lv = levels.view(t, c * z)
+    if out is not None:
+        # the block's warp writes min(tblock, T) x C x Z x Y x X pixels through out's pointer: refuse what cannot hold them
+        if (not out.is_cuda or out.device != stack.device or out.dtype != torch.uint16 or not out.is_contiguous()
+                or out.dim() != 5 or tuple(out.shape[1:]) != tuple(stack.shape[1:]) or out.shape[0] < min(tblock, t)):
+            raise ValueError("hot_path(tblock=...): out must be a contiguous uint16 tensor on the stack's device, "
+                             f"shaped (>= {min(tblock, t)},) + {tuple(stack.shape[1:])}")
     buf = out if out is not None else torch.empty((tblock,) + tuple(stack.shape[1:]), dtype=torch.uint16, device=stack.device)
     lib = _lib.load()
 

@@ -307,6 +307,37 @@ def phase_shift(ref: np.ndarray, mov: np.ndarray, upsample: bool = True, normali
     return float(cy), float(cx)
 
 
+def phase_shift_near_ties(ref: np.ndarray, mov: np.ndarray, rel: float = 1e-6) -> list:
+    """Every (dy, dx) that ``phase_shift`` would return if one of its two arg-max picks (integer peak, grid point)
+    fell on another candidate whose value lies within ``rel`` (relative to the spread of the surface) of the
+    maximum.  The refinement is a discontinuous function of its input at such ties: the pick decides which three
+    grid values each parabola goes through, and on an oblique ridge the neighbouring column's parabola has its
+    vertex somewhere else.  A float32 pipeline cannot be asked to break such a tie the way float64 does; the
+    randomised differential runs use this list to tell a tie from a miss (test infrastructure only)."""
+    r = cross_power(ref, mov, False)
+    ny, nx = r.shape
+    c = np.fft.ifft2(r).real
+    span = float(c.max() - c.min()) or 1.0
+    out = []
+    offs = np.arange(-UP_HALF, UP_HALF + 1) * UP_STEP
+    n = len(offs)
+    for k in np.flatnonzero(c.ravel() >= c.max() - rel * span):
+        py, px = divmod(int(k), nx)
+        sy = py - ny if py > ny // 2 else py
+        sx = px - nx if px > nx // 2 else px
+        v = _upsampled(r, sy + offs, sx + offs)
+        vspan = float(v.max() - v.min()) or 1.0
+        for g in np.flatnonzero(v.ravel() >= v.max() - rel * vspan):
+            iy, ix = divmod(int(g), n)
+            cy, cx = sy + offs[iy], sx + offs[ix]
+            if 0 < iy < n - 1:
+                cy += UP_STEP * _parabola(v[iy - 1, ix], v[iy, ix], v[iy + 1, ix])
+            if 0 < ix < n - 1:
+                cx += UP_STEP * _parabola(v[iy, ix - 1], v[iy, ix], v[iy, ix + 1])
+            out.append((float(cy), float(cx)))
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # a5: apply shift (cubic B-spline, mirror prefilter, zero outside), utility.py:351-355
 # --------------------------------------------------------------------------------------

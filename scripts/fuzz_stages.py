@@ -167,6 +167,9 @@ def f_smo_sigma(rng, dev):
     return f"smo_image {y}x{x} sigma={sig} size={size}"
 
 
+TIES = []
+
+
 def f_chan_shift(rng, dev):
     y, x = shape(rng, 64, 200)
     t, c, z = int(rng.integers(1, 3)), int(rng.integers(2, 4)), int(rng.choice([1, 1, 2]))
@@ -179,11 +182,18 @@ def f_chan_shift(rng, dev):
     out, sh = ops.chan_shift(ops.to_device_u16(st, dev), regc)
     sh = sh.cpu().numpy()
     eo, es = O.chan_shift_stack(st, regc)
-    # 0.01 px is the bar; planes below 256 px on a side are estimated on 64 / 128-point windows, where a broad peak
-    # between two DIFFERENT channels can be so flat that the half-precision spectra move its vertex by 0.02 px (seen
-    # once in ~1100 planes: DESIGN.md section 2)
-    tol = 0.01 if min(y, x) >= 256 else 0.03
-    assert np.abs(sh - es).max() < tol, ("chan_shift shifts", t, c, z, y, x, float(np.abs(sh - es).max()))
+    # 0.01 px is the bar everywhere (round 3: the Nyquist row's factor in the refinement, float spectra for windows
+    # below 256 points; 1500 planes of this run then agree outright).  A plane beyond it may still pass as a TIE of
+    # the refinement's own arg-max: two grid points whose values agree to 1e-6 of the surface's spread, where the
+    # pick decides which parabolas are used -- if the GPU's shift is within 0.01 px of what the ORACLE returns for
+    # one of the tied picks.  Ties are listed at the end of the run.
+    for f, ch, zz in zip(*np.nonzero(np.abs(sh - es).max(axis=-1) >= 0.01)):
+        cands = O.phase_shift_near_ties(st[f, regc, zz].astype(np.float64), st[f, ch, zz])
+        d = min(max(abs(sh[f, ch, zz, 0] - cy), abs(sh[f, ch, zz, 1] - cx)) for cy, cx in cands)
+        assert d < 0.01, ("chan_shift shifts", t, c, z, y, x, f, ch, zz, sh[f, ch, zz].tolist(), es[f, ch, zz].tolist(), len(cands))
+        sh[f, ch, zz] = es[f, ch, zz]
+        TIES.append((y, x))
+    assert np.abs(sh - es).max() < 0.01, ("chan_shift shifts", t, c, z, y, x, float(np.abs(sh - es).max()))
     out = ops.to_numpy_u16(out)
     for f in range(t):
         for ch in range(c):
@@ -247,14 +257,26 @@ STAGES = [f_bg_smo, f_blur, f_manual, f_measure, f_apply, f_edt, f_morph, f_stit
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 80
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    global SCALE
+    global SCALE, STAGES
     SCALE = float(sys.argv[3]) if len(sys.argv) > 3 else 1
+    if len(sys.argv) > 4:   # only the stages named, e.g. "chan_shift"
+        STAGES = [f for f in STAGES if f.__name__[2:] in sys.argv[4].split(",")]
     rng = np.random.default_rng(seed)
     dev = torch.device("cuda:0")
+    keep_going = bool(os.environ.get("FUZZ_KEEP_GOING"))   # list every miss instead of stopping at the first
+    misses = 0
     for k in range(n):
         fn = STAGES[k % len(STAGES)]
-        print(f"ok #{k} {fn(rng, dev)}", flush=True)
-    print("all", n, "cases agree")
+        try:
+            print(f"ok #{k} {fn(rng, dev)}", flush=True)
+        except AssertionError as e:
+            if not keep_going:
+                raise
+            misses += 1
+            print(f"MISS #{k} {e}", flush=True)
+    print("all", n, "cases agree" if not misses else f"cases run, {misses} misses", f"({len(TIES)} planes at an arg-max tie of the oracle's own refinement: {TIES})" if TIES else "")
+    if misses:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -78,6 +78,27 @@ def test_time_blocks_refuse_previous(dev):
         ops.hot_path(ops.to_device_u16(st, dev), ops.to_device_u16(lab, dev), THR, reg_ref="previous", tblock=2)
 
 
+def test_time_blocks_refuse_a_block_buffer_that_cannot_hold_a_block(dev):
+    """the block's warp writes through ``out``'s pointer: too few frames, another dtype, another plane shape, a
+    strided view or a host tensor are refused before any launch; a buffer of the right kind is used"""
+    t, c, y, x = 5, 2, 64, 96
+    st, _ = synth.make_stack(t, c, 1, y, x, n_cells=4, integer_drift=True, seed=3)
+    lab = _labels(t, 1, y, x, 3)
+    d, dl = ops.to_device_u16(st, dev), ops.to_device_u16(lab, dev)
+    bad = [torch.empty((2, c, 1, y, x), dtype=torch.uint16, device=dev),            # fewer frames than a block
+           torch.empty((3, c, 1, y, x), dtype=torch.int32, device=dev),             # wrong dtype
+           torch.empty((3, c, 1, y, x + 8), dtype=torch.uint16, device=dev),        # wrong plane shape
+           torch.empty((3, c, 1, y, 2 * x), dtype=torch.uint16, device=dev)[..., ::2],   # not contiguous
+           torch.empty((3, c, 1, y, x), dtype=torch.uint16)]                        # host memory
+    for out in bad:
+        with pytest.raises(ValueError, match="out must be"):
+            ops.hot_path(d, dl, THR, reg_ref="first", tblock=3, out=out)
+    good = torch.empty((3, c, 1, y, x), dtype=torch.uint16, device=dev)
+    a = ops.hot_path(d, dl, THR, reg_ref="first", tblock=3, out=good)
+    b = ops.hot_path(d, dl, THR, reg_ref="first", tblock=3)
+    assert torch.equal(a[1], b[1]) and all(torch.equal(p, q) for p, q in zip(a[0], b[0]))
+
+
 @pytest.mark.parametrize("reg_ref", ["first", "mean", "previous"])
 def test_single_frame_stack(dev, reg_ref):
     """T = 1: the frame is its own reference in every mode -> shift 0, the stack comes back background-subtracted"""
