@@ -991,14 +991,14 @@ __device__ __forceinline__ double row_weight(double sa, double ca, bool odd, con
 // The grid is evaluated as DIFFERENCES from its centre.  The refinement only looks at how the 225 values differ from
 // one another (arg-max, then a parabola through three neighbours), and on a broad correlation peak neighbouring values
 // differ by 1e-5 .. 1e-6 of their size: summed as they are in float32 they carry about that much rounding, and the
-// vertex moved by up to 0.02 px against the float64 oracle (small windows, broad blobs).  So the row weights of grid
+// vertex moved by up to 0.02 px against a float64 evaluation (small windows, broad blobs).  So the row weights of grid
 // row j != 7 are K(y'_j - y) - K(y'_7 - y), the column factors of grid column 7 +- m are exp(i phi m) - 1, both
 // formed before rounding to float; the sums are then small numbers with full relative precision:
 //   U[7][7] = V77,  U[j][7] = Vj7 - V77,  U[7][k] = V7k - V77,  U[j][k] = (Vjk - Vj7) - (V7k - V77)
 // and the finish kernel works on D[j][k] = Vjk - V77 = U[j][7] + U[7][k] + U[j][k] in double (V77 itself is not needed).
 //
 // T'[j] (j = 0..14) from the weighted row sums: acc[j] + e_j acc[15], y'_j = sy + 0.1 (j - 7).  acc[15] is the
-// Nyquist row R[Py/2][v], whose frequency counts as -Py/2 (fftfreq's convention, the oracle's and skimage's).  Its
+// Nyquist row R[Py/2][v], whose frequency counts as -Py/2 (fftfreq's convention, skimage's).  Its
 // factor is e_j = cos(pi y'_j) (- cos(pi y'_7) for j != 7), NOT exp(-i pi y'_j): the refinement sums the half
 // spectrum v <= Px/2 and doubles, which stands for the pair (u, v), (-u, -v) -- but the Nyquist row is its own
 // mirror image, its pair is (Py/2, v), (Py/2, -v), both with the SAME factor exp(-i pi y'), and their sum is
