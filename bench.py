@@ -49,6 +49,12 @@ WORKLOADS = {
     "c4fov": (300, 3, 1, 2048, 2048, 300, 0),  # one FOV of configs[3] (the plate is 64 of them, sharded over ranks)
     "c5": (64, 1, 1, 2048, 2048, 0, 0),        # configs[4]: 5041 labels per frame
 }
+# stage lines of the smoothing subsystem (north_star (1)): not the headline metric, one kernel each
+SMOOTHING = {
+    # name: (planes, Y, X, harness stage, dominant kernel)
+    "blur": (2000, 2048, 2048, "blur", "gauss_march_kernel"),           # blur_img, the reference's default (15, 15), sigma 5
+    "smosigma": (500, 2048, 2048, "smosigma", "gauss_reflect_tile_kernel"),   # SMO(sigma=1)'s gaussian pre-filter + levels
+}
 
 
 # algorithmic (compulsory) HBM bytes per stack pixel, SURVEY.md section 8(d)
@@ -294,12 +300,67 @@ def stage_traffic(dims, stages=("bg", "estimate", "apply", "measure")):
         return None, f"{type(e).__name__}: {e}"[:300]
 
 
+def bench_smoothing(args):
+    """`--workload blur | smosigma`: one stage of the smoothing subsystem on resident planes (utility.py:433-468 with
+    the defaults of experiments.py:337; SMO's sigma, utility.py:252), checked against the oracle on one plane, with
+    the kernel's counter traffic from the native harness.  One JSON line; not the headline metric."""
+    from imageanalysis_pipeline_amd import ops
+    from oracle import ref_path as O
+    n, y, x, hstage, kname = SMOOTHING[args.workload]
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    planes = (torch.poisson(torch.full((8, y, x), 100.0, device=dev), generator=g) + 400.0).to(torch.int32).to(torch.uint16)
+    planes = planes.repeat((n + 7) // 8, 1, 1)[:n].contiguous()
+    if args.workload == "blur":
+        step = lambda: ops.gauss_blur(planes, (15, 15), 5.0)          # noqa: E731
+        got = ops.to_numpy_u16(step()[3])
+        assert np.array_equal(got, O.gauss_blur(ops.to_numpy_u16(planes[3]), (15, 15), 5.0)), "blur differs from the oracle"
+        bpp, what = 4.0, "blur_img (15, 15) sigma 5: u16 -> u16, bit-exact vs the oracle on plane 3"
+    else:
+        thr = ops.smo_threshold((y, x), sigma=1.0, device=dev)
+        step = lambda: ops.bg_smo_levels(planes, thr, sigma=1.0)       # noqa: E731
+        lv = step()[0]
+        e = O.bg_smo(ops.to_numpy_u16(planes[3]), thr, 1.0, 7)[1]
+        assert abs(int(lv[3].item()) - e) <= 1, "level differs from the oracle"
+        bpp, what = 2.0, "smo_bg_sub levels with SMO(sigma=1): gaussian pre-filter + SMO march + median, level of plane 3 within half a count of the oracle"
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    px = n * y * x
+    out = {"metric": f"Mpx/s through {args.workload} (stage line, not the headline metric)", "value": px / ms / 1e3, "unit": "Mpx/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "u16 planes, f32 arithmetic", "data": "synthetic",
+           "config": {"workload": f"{args.workload}: {n} planes of {y}x{x} uint16; {what}"},
+           "hbm_frac_stage": bpp * px / (ms / 1e3) / HBM_PEAK, "algorithmic_bytes_per_px": bpp}
+    if not args.no_traffic:
+        del planes
+        torch.cuda.empty_cache()
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            import pmc_traffic
+            hn = min(n, 500)
+            got = pmc_traffic.measure([hstage, hn, y, x], timeout=150)
+            out["counter_traffic"] = {k: {"hbm_bytes_per_plane": v["hbm_bytes_per_harness_call"] / hn,
+                                          "fetch_bytes_per_plane": v["fetch_bytes_per_launch"] * v["hbm_bytes_per_harness_call"] / max(v["hbm_bytes_per_launch"], 1) / hn}
+                                      for k, v in got.items()}
+            out["harness_ms_per_call"] = next(iter(got.values())).get("harness_ms_per_call_under_profiler")
+        except Exception as e:  # noqa: BLE001
+            out["counter_traffic_note"] = f"{type(e).__name__}: {e}"[:300]
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + sorted(SMOOTHING))
     ap.add_argument("--frames", type=int, default=0, help="override T")
     ap.add_argument("--tblock", type=int, default=-1, help="frames registered + measured at a time (0: whole stack)")
     ap.add_argument("--reg-ref", default="mean", choices=["first", "mean", "previous"],
@@ -313,6 +374,8 @@ def main():
     ap.add_argument("--stage-report", action="store_true", help="also print a per-kernel table to stderr")
     args = ap.parse_args()
 
+    if args.workload in SMOOTHING:
+        return bench_smoothing(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))          # parent of the ranks: no GPU call has been made in this process
 

@@ -612,6 +612,52 @@ __global__ __launch_bounds__(256) void gauss_reflect_kernel(const T* __restrict_
   out[(size_t)plane * Y * X + idx] = acc / wsum;
 }
 
+// The same filter as one LDS-staged separable tile (radius <= 31, i.e. sigma <= 7.8; the plain kernel above stays for
+// wider ones): a 64 x 32 tile with its halo is staged once (values relative to the plane's first pixel), filtered
+// along y and then along x with precomputed, normalised taps -- no exponential per tap, no float plane between the
+// passes.
+struct ReflectTaps {
+  float w[32];   // w[k] = exp(-k^2 / 2 sigma^2) / sum, k = 0 .. radius
+};
+template <typename T>
+__global__ __launch_bounds__(256) void gauss_reflect_tile_kernel(const T* __restrict__ in, float* __restrict__ out,
+                                                                 int Y, int X, int radius, ReflectTaps taps) {
+  constexpr int TX = 64, TY = 32;
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x;
+  const int wx = TX + 2 * radius, hy = TY + 2 * radius;
+  float* tile = lds;                 // hy x wx
+  float* colp = lds + hy * wx;       // TY x wx after the y pass
+  const long long plane = blockIdx.z;
+  const int ox = blockIdx.x * TX, oy = blockIdx.y * TY;
+  const T* p = in + (size_t)plane * Y * X;
+  const float base = sizeof(T) == 2 ? (float)p[0] : 0.f;
+  for (int i = tid; i < hy * wx; i += 256) {
+    const int r = i / wx, c = i - r * wx;
+    const int yy = reflect_idx(oy + r - radius, Y), xx = reflect_idx(ox + c - radius, X);
+    tile[i] = (float)p[(size_t)yy * X + xx] - base;
+  }
+  __syncthreads();
+  for (int i = tid; i < TY * wx; i += 256) {   // y pass (scipy filters axis 0 first)
+    const int r = i / wx, c = i - r * wx;
+    const float* t = tile + (r + radius) * wx + c;
+    float s_ = taps.w[0] * t[0];
+    for (int k = 1; k <= radius; ++k) s_ += taps.w[k] * (t[-k * wx] + t[k * wx]);
+    colp[i] = s_;
+  }
+  __syncthreads();
+  for (int i = tid; i < TY * TX; i += 256) {
+    const int r = i / TX, c = i - r * TX;
+    const int yy = oy + r, xx = ox + c;
+    if (yy < Y && xx < X) {
+      const float* t = colp + r * wx + c + radius;
+      float s_ = taps.w[0] * t[0];
+      for (int k = 1; k <= radius; ++k) s_ += taps.w[k] * (t[-k] + t[k]);
+      out[(size_t)plane * Y * X + (size_t)yy * X + xx] = s_;
+    }
+  }
+}
+
 // ---- cv2.GaussianBlur semantics: LDS-staged separable tile, fp32, reflect-101, RNE+saturate ----
 constexpr int GB_TX = 64, GB_TY = 32, GB_MAXR = 31;
 
@@ -663,6 +709,152 @@ __global__ __launch_bounds__(256) void gauss_blur_kernel(const uint16_t* __restr
       r_ = fminf(fmaxf(r_, 0.f), 65535.f);
       out[(size_t)plane * Y * X + (size_t)yy * X + xx] = (uint16_t)r_;
     }
+  }
+}
+
+// The same arithmetic for the common square kernels (radius R <= 7: the reference's default is 15 x 15), marching:
+// a workgroup owns a strip of 128 columns and walks down it 32 rows a step.  The x-filtered rows live in an LDS
+// ring of 32 + 2R rows, so every source row is fetched and x-filtered once per strip (the tile kernel above
+// re-reads and re-filters its 2R halo rows for every 32-row tile: 44 % more at R = 7, and stages pixel by pixel).
+// A step's source rows arrive as unaligned 16-byte loads (8 pixels), requested a step ahead and kept in registers;
+// the x pass reads 8 + 2R neighbouring samples as three aligned 16-byte LDS vectors and produces 8 outputs from
+// registers, the y pass reads 8 + 2R ring rows of 2 columns and produces 2 x 8 outputs, stored 4 bytes per lane.  Every product and sum is rounded on its own (no FMA), in OpenCV's order: the bits of the
+// tile kernel.
+constexpr int GM_TX = 128, GM_TY = 32;
+template <int R> struct GmGeom {
+  static constexpr int SW = (GM_TX + 2 * R + 7) / 8 * 8;   // staged columns, from image column ox - R on
+  static constexpr int VPR = SW / 8;                        // 16-byte vectors per staged row
+  static constexpr int RH = GM_TY + 2 * R;                  // ring rows
+  static constexpr int NV = (GM_TY * VPR + 255) / 256;      // vectors a thread stages per step
+  static constexpr int XV = (8 + 2 * R + 7) / 8;            // vectors an x-pass item reads
+};
+typedef unsigned gm_u32x4 __attribute__((ext_vector_type(4)));
+typedef gm_u32x4 gm_u32x4_px __attribute__((aligned(2)));   // 16-byte load at any pixel address
+
+template <int R>
+__global__ __launch_bounds__(256, 4) void gauss_march_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
+                                                          int Y, int X, int band, GaussTaps taps) {
+  using G = GmGeom<R>;
+  __shared__ gm_u32x4 raw[GM_TY * G::VPR];                       // the step's source rows, u16
+  __shared__ __align__(16) float ring[G::RH * GM_TX];             // x-filtered rows, row = source row mod RH (from the band's first)
+  const int tid = threadIdx.x;
+  const long long plane = blockIdx.z;
+  const uint16_t* __restrict__ p = in + (size_t)plane * Y * X;
+  uint16_t* __restrict__ po = out + (size_t)plane * Y * X;
+  // strips next to each other (consecutive ids) run on one XCD: the lines they share come from one L2
+  const unsigned lin = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+  const int ox = (lin % gridDim.x) * GM_TX;
+  const int y0 = (lin / gridDim.x) * band, y1 = min(Y, y0 + band);
+  const int first = ox - R;                                       // image column of staged column 0
+  const bool cols_inside = first >= 0 && first + G::SW <= X;      // (uniform) no mirrored column in this strip
+  float tx[R + 1], ty[R + 1];
+#pragma unroll
+  for (int k = 0; k <= R; ++k) { tx[k] = taps.x[k]; ty[k] = taps.y[k]; }
+
+  // staged vector i of a step: row i / VPR, vector i % VPR; source row `src0 + row` (mirrored outside the plane)
+  auto fetch = [&](int i, int src0) -> gm_u32x4 {
+    const int r = i / G::VPR, v = i - r * G::VPR;
+    const int yy = src0 + r;
+    const size_t ro = (size_t)((unsigned)yy < (unsigned)Y ? yy : reflect101_idx(yy, Y)) * X;
+    const int c0 = first + 8 * v;
+    if (cols_inside) return *reinterpret_cast<const gm_u32x4_px*>(p + ro + c0);
+    unsigned e[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e[k] = p[ro + reflect101_idx(c0 + k, X)];
+    return (gm_u32x4){e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+  };
+  // x pass over `nrows` staged rows; staged row r is source row src0 + r and goes to ring row (src0 + r - (y0 - R)) mod RH.
+  // An item is 8 outputs of TWO rows (r and r + nrows / 2) worked as packed pairs: v_pk_mul / v_pk_add round each
+  // product and sum like their scalar forms and cost 1.4x one scalar instruction for two.
+  auto xpass = [&](int nrows, int src0) {
+    const int half = nrows / 2;
+    for (int i = tid; i < half * (GM_TX / 8); i += 256) {
+      const int r = i / (GM_TX / 8), g = i - r * (GM_TX / 8);
+      const gm_u32x4* ta = raw + r * G::VPR + g;
+      const gm_u32x4* tb = ta + half * G::VPR;
+      v2f smp[8 * G::XV];
+#pragma unroll
+      for (int v = 0; v < G::XV; ++v) {
+        const gm_u32x4 qa = ta[v], qb = tb[v];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          smp[8 * v + 2 * k] = (v2f){(float)(qa[k] & 0xffffu), (float)(qb[k] & 0xffffu)};
+          smp[8 * v + 2 * k + 1] = (v2f){(float)(qa[k] >> 16), (float)(qb[k] >> 16)};
+        }
+      }
+      v2f o[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        v2f s_ = (v2f){tx[0], tx[0]} * smp[c + R];
+#pragma unroll
+        for (int k = 1; k <= R; ++k) s_ = s_ + (v2f){tx[k], tx[k]} * (smp[c + R - k] + smp[c + R + k]);
+        o[c] = s_;
+      }
+      const int ra = (src0 + r - (y0 - R)) % G::RH, rb = (src0 + r + half - (y0 - R)) % G::RH;
+      float4* da = reinterpret_cast<float4*>(ring + ra * GM_TX + 8 * g);
+      float4* db = reinterpret_cast<float4*>(ring + rb * GM_TX + 8 * g);
+      da[0] = make_float4(o[0].x, o[1].x, o[2].x, o[3].x);
+      da[1] = make_float4(o[4].x, o[5].x, o[6].x, o[7].x);
+      db[0] = make_float4(o[0].y, o[1].y, o[2].y, o[3].y);
+      db[1] = make_float4(o[4].y, o[5].y, o[6].y, o[7].y);
+    }
+  };
+
+  // lead-in: the 2R rows above the first step's new rows
+  gm_u32x4 q[G::NV];
+  {
+    if (tid < 2 * R * G::VPR) raw[tid] = fetch(tid, y0 - R);
+    static_assert(2 * R * G::VPR <= 256, "the lead-in is one round of staging");
+#pragma unroll
+    for (int jv = 0; jv < G::NV; ++jv) {
+      const int i = tid + jv * 256;
+      if (i < GM_TY * G::VPR) q[jv] = fetch(i, y0 + R);
+    }
+    __syncthreads();
+    xpass(2 * R, y0 - R);
+    __syncthreads();
+  }
+  for (int oy = y0; oy < y1; oy += GM_TY) {
+    // the step's new source rows oy + R .. oy + R + 31 (already in registers) -> LDS
+#pragma unroll
+    for (int jv = 0; jv < G::NV; ++jv) {
+      const int i = tid + jv * 256;
+      if (i < GM_TY * G::VPR) raw[i] = q[jv];
+    }
+    __syncthreads();
+    if (oy + GM_TY < y1) {
+#pragma unroll
+      for (int jv = 0; jv < G::NV; ++jv) {
+        const int i = tid + jv * 256;
+        if (i < GM_TY * G::VPR) q[jv] = fetch(i, oy + GM_TY + R);
+      }
+    }
+    xpass(GM_TY, oy + R);
+    __syncthreads();
+    // y pass: 2 columns x 8 rows per thread (a wave = 128 columns of one 8-row group: 256-byte stores)
+    {
+      const int cp = tid & 63, rg = tid >> 6;
+      const int ya = oy + 8 * rg;                       // first output row of this thread
+      int rr = (ya - R - (y0 - R)) % G::RH;             // ring row of source row ya - R
+      v2f col[8 + 2 * R];
+#pragma unroll
+      for (int i = 0; i < 8 + 2 * R; ++i) {
+        col[i] = *reinterpret_cast<const v2f*>(ring + rr * GM_TX + 2 * cp);
+        rr = rr + 1 == G::RH ? 0 : rr + 1;
+      }
+      const int xx = ox + 2 * cp;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        v2f s_ = (v2f){ty[0], ty[0]} * col[r + R];
+#pragma unroll
+        for (int k = 1; k <= R; ++k) s_ = s_ + (v2f){ty[k], ty[k]} * (col[r + R - k] + col[r + R + k]);
+        const float res[2] = {fminf(fmaxf(rintf(s_.x), 0.f), 65535.f), fminf(fmaxf(rintf(s_.y), 0.f), 65535.f)};
+        const int yy = ya + r;
+        if (yy < y1 && xx < X)   // X is even: both columns of the pair are inside
+          __builtin_nontemporal_store((unsigned)res[0] | ((unsigned)res[1] << 16), reinterpret_cast<unsigned*>(po + (size_t)yy * X + xx));
+      }
+    }
+    __syncthreads();   // the ring rows this step read may be overwritten by the next
   }
 }
 
@@ -718,6 +910,20 @@ template <typename T>
 static int launch_gauss_reflect(const T* in, float* tmp, float* out, int64_t n, int Y, int X, float sigma,
                                 hipStream_t st) {
   int radius = (int)(4.0f * sigma + 0.5f);
+  if (radius <= 31) {   // one tile kernel, taps worked out here
+    ReflectTaps h;
+    double sum = 1.0;
+    for (int k = 1; k <= radius; ++k) sum += 2.0 * exp(-0.5 * (double)(k * k) / ((double)sigma * sigma));
+    for (int k = 0; k < 32; ++k) h.w[k] = k <= radius ? (float)(exp(-0.5 * (double)(k * k) / ((double)sigma * sigma)) / sum) : 0.f;
+    const size_t lds = ((size_t)(32 + 2 * radius) * (64 + 2 * radius) + (size_t)32 * (64 + 2 * radius)) * 4;
+    if (lds > 48 * 1024)
+      IAP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_reflect_tile_kernel<T>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((X + 63) / 64, (Y + 31) / 32, (unsigned)n);
+    { ProfScope ps_(K_GAUSS, st); hipLaunchKernelGGL((gauss_reflect_tile_kernel<T>), grid, dim3(256), lds, st, in, out, Y, X, radius, h); }
+    IAP_LAUNCH_CHECK();
+    return IAP_OK;
+  }
   unsigned bx = (unsigned)(((long long)Y * X + 255) / 256);
   { ProfScope ps_(K_GAUSS, st); hipLaunchKernelGGL((gauss_reflect_kernel<T>), dim3(bx, (unsigned)n), dim3(256), 0, st, in, tmp, Y, X, 0,
                      radius, sigma); }
@@ -966,6 +1172,20 @@ extern "C" int iap_gauss_blur_u16(const uint16_t* in, uint16_t* out, int64_t n, 
   fill(kx, sigma, h.x);
   fill(ky, sigma, h.y);
   int rx = (kx - 1) / 2, ry = (ky - 1) / 2;
+  if (rx == ry && rx >= 1 && rx <= 7 && X % 2 == 0 && X >= 8) {   // marching kernel (4-byte stores need even rows)
+    // bands of 256 rows (8 steps): the lead-in is 2R of them; shorter bands only while the launch would not fill the chip
+    int band = 256;
+    while (band > GM_TY && (long long)((X + GM_TX - 1) / GM_TX) * ((Y + band - 1) / band) * n < 2048) band >>= 1;
+    dim3 grid((X + GM_TX - 1) / GM_TX, (Y + band - 1) / band, (unsigned)n);
+    ProfScope ps_(K_GAUSS, st);
+    switch (rx) {
+#define IAP_GM(R_) case R_: hipLaunchKernelGGL(gauss_march_kernel<R_>, grid, dim3(256), 0, st, in, out, Y, X, band, h); break;
+      IAP_GM(1) IAP_GM(2) IAP_GM(3) IAP_GM(4) IAP_GM(5) IAP_GM(6) IAP_GM(7)
+#undef IAP_GM
+    }
+    IAP_LAUNCH_CHECK();
+    return IAP_OK;
+  }
   size_t lds = ((size_t)(GB_TY + 2 * ry) * (GB_TX + 2 * rx) + (size_t)(GB_TY + 2 * ry) * GB_TX + rx + ry + 2) * 4;
   dim3 grid((X + GB_TX - 1) / GB_TX, (Y + GB_TY - 1) / GB_TY, (unsigned)n);
   if (lds > 48 * 1024)   // kernels of 57 and up pass the default 64 KB of dynamic LDS (71 KB at 63): ask for it

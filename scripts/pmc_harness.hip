@@ -5,6 +5,8 @@
 //   pmc_harness bg       <planes> [Y X]         iap_bg_smo_u16, levels only (what bench.py times)
 //   pmc_harness estimate <frames> [Y X]         iap_reg_estimate_u16 (r2c, cols, c2r, upsample kernels), 64-frame groups
 //   pmc_harness measure  <frames> <C> [Y X] [dense]   iap_measure_labels_u16; 300 discs per frame, or the 5041-label grid
+//   pmc_harness blur     <planes> [Y X]         iap_gauss_blur_u16, the reference's default (15, 15), sigma 5 (experiments.py:337)
+//   pmc_harness smosigma <planes> [Y X]         iap_bg_smo_u16 with SMO's gaussian pre-filter, sigma 1 (levels only)
 // Prints the mean wall time per call (HIP events) so a run without the profiler doubles as a micro-benchmark.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -138,6 +140,24 @@ int main(int argc, char** argv) {
     IAP(iap_bg_smo_u16(in, nullptr, n, Y, X, 0.f, 7, 0.0455f, med2, nullptr, ws, wsb, nullptr));
     CK(hipEventRecord(e0));
     for (int k = 0; k < reps; ++k) IAP(iap_bg_smo_u16(in, nullptr, n, Y, X, 0.f, 7, 0.0455f, med2, nullptr, ws, wsb, nullptr));
+    CK(hipEventRecord(e1));
+  } else if (!strcmp(stage, "blur")) {
+    uint16_t* out;
+    CK(hipMalloc(&out, (size_t)planes * px * 2));
+    const int k = getenv("IAP_HARNESS_BLUR_K") ? atoi(getenv("IAP_HARNESS_BLUR_K")) : 15;
+    IAP(iap_gauss_blur_u16(in, out, n, Y, X, k, k, 5.0, nullptr));
+    CK(hipEventRecord(e0));
+    for (int r = 0; r < reps; ++r) IAP(iap_gauss_blur_u16(in, out, n, Y, X, k, k, 5.0, nullptr));
+    CK(hipEventRecord(e1));
+  } else if (!strcmp(stage, "smosigma")) {
+    const size_t wsb = iap_bg_smo_ws_bytes(n, Y, X, 1.0f);
+    void* ws;
+    int32_t* med2;
+    CK(hipMalloc(&ws, wsb));
+    CK(hipMalloc(&med2, (size_t)n * 4));
+    IAP(iap_bg_smo_u16(in, nullptr, n, Y, X, 1.0f, 7, 0.0455f, med2, nullptr, ws, wsb, nullptr));
+    CK(hipEventRecord(e0));
+    for (int k = 0; k < reps; ++k) IAP(iap_bg_smo_u16(in, nullptr, n, Y, X, 1.0f, 7, 0.0455f, med2, nullptr, ws, wsb, nullptr));
     CK(hipEventRecord(e1));
   } else if (!strcmp(stage, "estimate")) {
     const int batch = (int)(n < 64 ? n : 64);

@@ -94,7 +94,8 @@ def measure(harness_args, timeout=120, keep=None):
     return out
 
 
-ALL = (["apply", 500, 4], ["bg", 2000], ["estimate", 128], ["measure", 500, 4], ["measure", 64, 1, 2048, 2048, "dense"])
+ALL = (["apply", 500, 4], ["bg", 2000], ["estimate", 128], ["measure", 500, 4], ["measure", 64, 1, 2048, 2048, "dense"],
+       ["blur", 500], ["smosigma", 200])
 
 
 if __name__ == "__main__":
