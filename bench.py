@@ -48,6 +48,7 @@ WORKLOADS = {
     "c3": (200, 2, 31, 2048, 2048, 300, 20),   # configs[2]: 104 GB stack, registered + measured 20 frames at a time
     "c4fov": (300, 3, 1, 2048, 2048, 300, 0),  # one FOV of configs[3] (the plate is 64 of them, sharded over ranks)
     "c5": (64, 1, 1, 2048, 2048, 0, 0),        # configs[4]: 5041 labels per frame
+    "c4": (300, 3, 1, 2048, 2048, 300, 0),     # configs[3] as the plate it is: 64 such FOVs sharded over the ranks (bench_plate)
 }
 # stage lines of the smoothing subsystem (north_star (1)): not the headline metric, one kernel each
 SMOOTHING = {
@@ -300,6 +301,108 @@ def stage_traffic(dims, stages=("bg", "estimate", "apply", "measure")):
         return None, f"{type(e).__name__}: {e}"[:300]
 
 
+def bench_plate(args, rank, world, dev, backend):
+    """`--workload c4`: BASELINE configs[3], the 64-FOV plate (core.py:99-112, 327-337 are the loops it replaces).
+    One step = the whole plate through distributed.process_plate: every rank runs the hot path on its block of
+    FOVs, one variable-length gather of the per-cell rows per step.  A rank keeps `--resident-fovs` distinct
+    synthetic FOVs in HBM and maps its block onto them cyclically (at 8 ranks a block is 8 FOVs = 60 GB and all can
+    be resident; at 1 rank the 483 GB plate cannot, so the resident ones are each processed several times -- the
+    work of 64 FOVs, inputs resident as the metric asks).  N = 1 also times the STREAMED form on a few FOVs: pinned
+    host copies uploaded into two device buffers on a side stream while the previous FOV computes (PCIe-inclusive,
+    reported beside `value`, never as it)."""
+    import torch.distributed as dist
+    from imageanalysis_pipeline_amd import distributed as D, ops
+    t, c, z, y, x, n_cells, _ = WORKLOADS["c4"]
+    if args.frames:
+        t = args.frames
+    n_fov = args.fovs
+    mine = list(D.shard_fovs(n_fov, rank, world))
+    nres = max(1, min(len(mine), args.resident_fovs))
+    resident = [make_device_stack(t, c, z, y, x, n_cells, dev, seed=1000 + mine[k])[:2] for k in range(nres)] if mine else []
+    thr = ops.smo_threshold((y, x), device=dev)
+
+    def load(i, slot=None):
+        return resident[(i - mine[0]) % nres]
+
+    def step():
+        return D.process_plate(load, n_fov, thr, reg_ref=args.reg_ref)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rows = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    px_fov = t * c * z * y * x
+    value = px_fov * n_fov * args.steps / dt / 1e6
+    bpp = sum(stage_bytes_per_px(c).values())
+    out = None
+    if rank == 0:
+        out = {"metric": "Mpx/s through bg-sub+registration+mask measure", "value": value, "unit": "Mpx/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+               "config": {"workload": f"c4: plate of {n_fov} FOVs, T={t} C={c} {y}x{x} uint16 each, sub-pixel drift, {n_cells} labels/frame, "
+                                      f"reg_ref={args.reg_ref}; FOVs block-sharded over {world} rank(s), {nres} distinct FOV(s) resident per rank",
+                          "parallelism": f"fov-shard x{world}, one all_gather of the row tables per step"},
+               "rows_gathered": int(rows.shape[0]), "ms_per_fov": dt / args.steps * 1e3 / max(len(mine), 1),
+               "hbm_frac_end_to_end": value * 1e6 / world * bpp / HBM_PEAK, "algorithmic_bytes_per_px": bpp}
+    if world == 1 and not args.no_verify:
+        # FOV 0's rows equal a direct call of the hot path on it (bit for bit); the path itself against the oracle
+        tables, _, _ = ops.hot_path(resident[0][0], resident[0][1], thr, 0, args.reg_ref)
+        direct = D.pack_rows(tables, mine[0])
+        got = rows[rows[:, 0] == float(mine[0])]
+        assert got.shape == direct.shape and bool((got == direct).all()), "plate rows of FOV 0 differ from a direct call"
+        pth = Path(resident[0][0], resident[0][1], args.reg_ref)
+        pth.step()
+        out["verified"] = verify(pth)
+        out["verified"]["plate"] = "rows of the first FOV equal a direct ops.hot_path call on it, bit for bit"
+        del pth
+    if world == 1 and args.streamed_fovs > 0:
+        # the streamed form: host-resident FOVs (pinned), two device slots, upload of FOV k+1 under the compute of FOV k
+        ns = args.streamed_fovs
+        host = [(st.cpu().pin_memory(), lab.cpu().pin_memory()) for st, lab in resident[: min(nres, 2)]]
+        slots = [(torch.empty_like(resident[0][0]), torch.empty_like(resident[0][1])) for _ in range(2)]
+
+        def upload(i, slot=0):
+            hs, hl = host[i % len(host)]
+            slots[slot][0].copy_(hs, non_blocking=True)
+            slots[slot][1].copy_(hl, non_blocking=True)
+            return slots[slot]
+
+        D.process_plate(upload, 2, thr, reg_ref=args.reg_ref, prefetch=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        srows = D.process_plate(upload, ns, thr, reg_ref=args.reg_ref, prefetch=True)
+        torch.cuda.synchronize()
+        sdt = time.perf_counter() - t1
+        t2 = time.perf_counter()
+        D.process_plate(upload, ns, thr, reg_ref=args.reg_ref, prefetch=False)
+        torch.cuda.synchronize()
+        sdt_serial = time.perf_counter() - t2
+        fov_bytes = resident[0][0].numel() * 2 + resident[0][1].numel() * 2
+        out["streamed"] = {"fovs": ns, "ms_per_fov": sdt / ns * 1e3, "ms_per_fov_without_overlap": sdt_serial / ns * 1e3,
+                           "host_to_device_GBps": fov_bytes * ns / sdt / 1e9, "Mpx_per_s": px_fov * ns / sdt / 1e6,
+                           "rows": int(srows.shape[0]),
+                           "note": "PCIe-inclusive: pinned host FOVs -> two device slots on a side stream, FOV k+1 uploading "
+                                   "while FOV k computes (distributed.process_plate(prefetch=True)); the 483 GB plate does not "
+                                   "fit one GPU, this is what a 1-GPU run of it costs per FOV"}
+    if world > 1:
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
 def bench_smoothing(args):
     """`--workload blur | smosigma`: one stage of the smoothing subsystem on resident planes (utility.py:433-468 with
     the defaults of experiments.py:337; SMO's sigma, utility.py:252), checked against the oracle on one plane, with
@@ -372,6 +475,9 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-traffic", action="store_true")
     ap.add_argument("--stage-report", action="store_true", help="also print a per-kernel table to stderr")
+    ap.add_argument("--fovs", type=int, default=64, help="c4: fields of view on the plate")
+    ap.add_argument("--resident-fovs", type=int, default=4, help="c4: distinct synthetic FOVs a rank keeps in HBM")
+    ap.add_argument("--streamed-fovs", type=int, default=8, help="c4, N=1: FOVs of the streamed (host -> device) form; 0: skip")
     args = ap.parse_args()
 
     if args.workload in SMOOTHING:
@@ -404,6 +510,8 @@ def main():
         if rank == 0 and world != args.gpus:
             print(f"bench.py: --gpus {args.gpus} but the launcher formed a world of {world}", file=sys.stderr)
 
+    if args.workload == "c4":
+        return bench_plate(args, rank, world, dev, backend)
     t, c, z, y, x, n_cells, tblock = WORKLOADS[args.workload]
     if args.frames:
         t = args.frames

@@ -59,17 +59,49 @@ def gather_rows(rows: torch.Tensor, group=None) -> torch.Tensor:
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], 0)
 
 
-def process_plate(load_fov, n_fov: int, threshold: float, reg_ref: str = "mean", reg_channel: int = 0, group=None):
+def process_plate(load_fov, n_fov: int, threshold: float, reg_ref: str = "mean", reg_channel: int = 0, group=None,
+                  prefetch: bool = False):
     """Runs bg_smo -> im_reg -> measure on this rank's shard of the plate and gathers the rows.
-    ``load_fov(i)`` returns (stack u16 (T,C,Z,Y,X), labels u16 (T,Z,Y,X)) as device tensors."""
+    ``load_fov(i)`` returns (stack u16 (T,C,Z,Y,X), labels u16 (T,Z,Y,X)) as device tensors.
+
+    ``prefetch``: FOV k+1 is loaded on a side stream while FOV k computes (a plate that does not fit the GPU is
+    streamed through two buffers: SURVEY 8e).  The loader is then called as ``load_fov(i, slot)`` with slot = 0 / 1
+    alternating and may reuse one pair of buffers per slot: the side stream waits until the FOV that used the slot
+    last has been measured before the loader is called again for it, and the compute stream waits for the load."""
     from . import ops
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     parts = []
-    for i in shard_fovs(n_fov, rank, world):
-        stack, labels = load_fov(i)
-        tables, _, _ = ops.hot_path(stack, labels, threshold, reg_channel, reg_ref)   # bg levels, im_reg, measure
-        parts.append(pack_rows(tables, i))
+    mine = list(shard_fovs(n_fov, rank, world))
+    if prefetch and mine and torch.cuda.is_available():
+        main = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        loaded = [torch.cuda.Event(), torch.cuda.Event()]     # slot's FOV is in its buffers
+        free = [torch.cuda.Event(), torch.cuda.Event()]       # slot's FOV has been consumed
+
+        def start_load(k):
+            slot = k % 2
+            with torch.cuda.stream(side):
+                if k >= 2:
+                    side.wait_event(free[slot])
+                got = load_fov(mine[k], slot)
+                loaded[slot].record(side)
+            return got
+
+        nxt = start_load(0)
+        for k, i in enumerate(mine):
+            stack, labels = nxt
+            if k + 1 < len(mine):
+                nxt = start_load(k + 1)
+            main.wait_event(loaded[k % 2])
+            tables, _, _ = ops.hot_path(stack, labels, threshold, reg_channel, reg_ref)
+            free[k % 2].record(main)
+            parts.append(pack_rows(tables, i))
+    else:
+        for i in mine:
+            stack, labels = load_fov(i)
+            tables, _, _ = ops.hot_path(stack, labels, threshold, reg_channel, reg_ref)   # bg levels, im_reg, measure
+            parts.append(pack_rows(tables, i))
     if parts:
         rows = torch.cat(parts, 0)
     else:
@@ -95,7 +127,7 @@ def reference_plane(planes: torch.Tensor, t0: int, n_frames: int, reg_ref: str, 
     """The plane every frame is registered against (utility.py:332-366), from this rank's (MIP) planes
     u16 (tb, Y, X) of the registration channel, frames t0 .. t0+tb-1 of n_frames.
     'first': frame 0's plane, broadcast by the rank that holds it -> u16 (Y, X).
-    'mean':  sum over all frames (exact int32 sums, all-reduced) times float32(1/n_frames) -> f32 (Y, X),
+    'mean':  sum over all frames (exact int64 sums, all-reduced) times float32(1/n_frames) -> f32 (Y, X),
              the very values iap_im_reg_u16 feeds its reference spectrum (sum as f32, scaled on load)."""
     if reg_ref not in ("first", "mean"):
         raise ValueError(f"time blocks cannot shard reg_ref={reg_ref!r} ('previous' is serial in time)")
@@ -115,8 +147,9 @@ def reference_plane(planes: torch.Tensor, t0: int, n_frames: int, reg_ref: str, 
         dist.broadcast(buf, src=dist.get_global_rank(group, int(src.item())) if group is not None else int(src.item()),
                        group=group)
         return buf.to(dev).view(torch.uint16)
-    total = planes.to(torch.int32).sum(dim=0, dtype=torch.int32) if planes.shape[0] else \
-        torch.zeros(planes.shape[1:], dtype=torch.int32, device=dev)
+    # (int64: 32768 frames of saturated pixels would pass int32; the library's own 'mean' path sums in u32)
+    total = planes.to(torch.int32).sum(dim=0, dtype=torch.int64) if planes.shape[0] else \
+        torch.zeros(planes.shape[1:], dtype=torch.int64, device=dev)
     if multi:
         if host:
             total = total.cpu()

@@ -60,6 +60,29 @@ def test_process_plate_single_rank_c4_shaped(dev, reg_ref):
         assert pos == len(mine)
 
 
+def test_process_plate_streamed_through_two_slots(dev):
+    """prefetch=True: FOV k+1 is copied into the other of two reusable device slots on a side stream while FOV k
+    computes (a plate that does not fit the GPU); the rows equal the plain loop's, bit for bit, although every
+    slot is overwritten several times"""
+    thr = O.smo_threshold((Y, X))
+    nfov = 7
+    host = [tuple(t.cpu().pin_memory() for t in _fov(i, dev)[2:]) for i in range(nfov)]
+    slots = [(torch.empty((T, C, 1, Y, X), dtype=torch.uint16, device=dev), torch.empty((T, 1, Y, X), dtype=torch.uint16, device=dev))
+             for _ in range(2)]
+    seen = []
+
+    def upload(i, slot):
+        seen.append((i, slot))
+        slots[slot][0].copy_(host[i][0], non_blocking=True)
+        slots[slot][1].copy_(host[i][1], non_blocking=True)
+        return slots[slot]
+
+    rows = D.process_plate(upload, nfov, thr, reg_ref="mean", prefetch=True)
+    assert seen == [(i, i % 2) for i in range(nfov)]
+    ref = D.process_plate(lambda i: _fov(i, dev)[2:], nfov, thr, reg_ref="mean")
+    assert torch.equal(rows, ref)
+
+
 @pytest.mark.parametrize("reg_ref", ["mean", "first"])
 def test_process_fov_timeblocks_single_rank(dev, reg_ref):
     thr = O.smo_threshold((Y, X))
@@ -81,6 +104,14 @@ def _free_port():
 
 
 def _worker(rank, world, port, q):
+    try:
+        _worker_body(rank, world, port, q)
+    except BaseException as e:  # noqa: BLE001  (the parent must learn why a rank died instead of timing out)
+        q.put((rank, f"{type(e).__name__}: {e}"))
+        raise
+
+
+def _worker_body(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)      # gloo: both ranks sit on the one GPU here
     try:
@@ -103,10 +134,19 @@ def test_two_ranks_equal_one_process(dev):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=170) for _ in range(world)), key=lambda r: r[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        res = [q.get(timeout=170) for _ in range(world)]
+        for r in res:
+            assert len(r) == 4, f"rank {r[0]} failed: {r[1]}"
+        res.sort(key=lambda r: r[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:          # no rank outlives the test holding the GPU
+            if p.is_alive():
+                p.terminate()
+                p.join(timeout=10)
     thr = O.smo_threshold((Y, X))
     ref = _sequential_rows(dev, thr, "mean", range(5)).cpu().numpy()
     _, _, st, lab = _fov(0, dev)
