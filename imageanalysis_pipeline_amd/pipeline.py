@@ -46,18 +46,115 @@ def _write_u16_planes(paths, planes):
     write_planes(paths, np.ascontiguousarray(planes, dtype=np.uint16))
 
 
+class _ResidentPlanes:
+    """Planes the shim has just read or written stay on the GPU, so that consecutive calls on the same folders
+    (smo_bg_sub -> im_reg -> extract_channelData, core.py:99-112, 327-337) cost one folder read and two folder
+    writes instead of three reads and two writes.  An entry belongs to one folder and remembers, per file, the
+    size and modification time the file had when the shim last touched it: a request is served from the GPU only if
+    every requested file still carries them (any external write, deletion or new file of that name drops the
+    entry), and only whole planes the shim itself produced or read are kept.  Bounded by ``IAP_SHIM_RESIDENT_GB``
+    (default 48; 0 switches it off): the oldest folders go first."""
+
+    def __init__(self):
+        import threading
+        self._lock = threading.Lock()
+        self._entries = {}          # folder -> (index {path: row}, sig {path: (size, mtime_ns)}, planes (n, Y, X), device)
+        self.hits = self.misses = 0
+
+    @staticmethod
+    def _limit():
+        import os
+        try:
+            return float(os.environ.get("IAP_SHIM_RESIDENT_GB", "48")) * 1e9
+        except ValueError:
+            return 48e9
+
+    @staticmethod
+    def _sig(path):
+        import os
+        st = os.stat(path)
+        return (st.st_size, st.st_mtime_ns)
+
+    def get(self, paths, dev):
+        if not paths or self._limit() <= 0:
+            return None
+        from os.path import dirname
+        folder = dirname(paths[0])
+        with self._lock:
+            e = self._entries.get(folder)
+            if e is None or e[3] != dev:
+                self.misses += 1
+                return None
+            index, sig, planes, _ = e
+            try:
+                rows = [index[p] for p in paths]
+                fresh = all(self._sig(p) == sig[p] for p in paths)
+            except (KeyError, OSError):
+                fresh = False
+            if not fresh:
+                del self._entries[folder]       # somebody else wrote there: forget the folder
+                self.misses += 1
+                return None
+            self.hits += 1
+            self._entries[folder] = self._entries.pop(folder)    # most recently used
+            if rows == list(range(planes.shape[0])):
+                return planes
+            return planes.index_select(0, torch.tensor(rows, dtype=torch.int64, device=planes.device))
+
+    def put(self, paths, planes):
+        """planes (n, Y, X) device u16 = the current contents of the files ``paths`` (just read or just written)"""
+        limit = self._limit()
+        if not paths or limit <= 0:
+            return
+        from os.path import dirname
+        folder = dirname(paths[0])
+        nbytes = planes.numel() * 2
+        with self._lock:
+            self._entries.pop(folder, None)
+            if nbytes > limit or any(dirname(p) != folder for p in paths):
+                return
+            try:
+                sig = {p: self._sig(p) for p in paths}
+            except OSError:
+                return
+            self._entries[folder] = ({p: i for i, p in enumerate(paths)}, sig, planes, planes.device)
+            while sum(e[2].numel() * 2 for e in self._entries.values()) > limit and len(self._entries) > 1:
+                self._entries.pop(next(iter(self._entries)))
+
+    def drop(self, folder):
+        """before planes served from here are modified in place"""
+        with self._lock:
+            self._entries.pop(folder, None)
+
+    def clear(self):
+        with self._lock:
+            self._entries.clear()
+
+
+RESIDENT = _ResidentPlanes()
+
+
 def _planes_to_device(paths, dev):
-    """n plane files -> device u16 (n, Y, X): file reads into pinned blocks overlapped with their upload
-    (tiffio.read_planes_to_device); files the batched reader does not take go through the generic one."""
+    """n plane files -> device u16 (n, Y, X): served from the GPU when the shim itself read or wrote exactly these
+    files last and nobody touched them since (_ResidentPlanes), else file reads into pinned blocks overlapped with
+    their upload (tiffio.read_planes_to_device); files the batched reader does not take go through the generic one."""
+    got = RESIDENT.get(paths, dev)
+    if got is not None:
+        return got
     try:
-        return read_planes_to_device(paths, dev)
+        planes = read_planes_to_device(paths, dev)
     except ValueError:
-        return ops.to_device_u16(np.stack([imread(p) for p in paths]).astype(np.uint16), dev)
+        planes = ops.to_device_u16(np.stack([imread(p) for p in paths]).astype(np.uint16), dev)
+    RESIDENT.put(paths, planes)
+    return planes
 
 
 def _planes_from_device(paths, planes):
-    """device u16 planes (any leading shape, one path per plane) -> files, downloads overlapped with the writes"""
-    write_planes_from_device(paths, planes.reshape(-1, *planes.shape[-2:]))
+    """device u16 planes (any leading shape, one path per plane) -> files, downloads overlapped with the writes;
+    the planes stay resident as the folder's contents"""
+    flat = planes.reshape(-1, *planes.shape[-2:])
+    write_planes_from_device(paths, flat)
+    RESIDENT.put(paths, flat)
 
 
 class Utility:
@@ -213,6 +310,7 @@ class Utility:
         if names:
             paths = [join(sep, imgFold_path + sep, f) for f in names]
             d = _planes_to_device(paths, dev)
+            RESIDENT.drop(imgFold_path)     # d is about to change under the folder's old signature
             thr = ops.smo_threshold(tuple(d.shape[-2:]), sigma=sigma, size=size, seed=seed, device=dev)
             out, _, _ = ops.bg_smo(d, thr, sigma=sigma, size=size, out=d)     # in place, as the reference
             _planes_from_device(paths, out)
@@ -562,26 +660,34 @@ class Analysis(Utility):
             for chan, lst in by_chan.items():
                 d = {k: [] for k in keys}
                 tables = [self._measure(img_stack, self._label_stack(folder, chan, shape)) for folder, shape in lst]
+                # analysis.py:74-98 appends row by row (frame, mask set, object; per row the channel columns in the order
+                # "for chan: for name"); the same lists are filled a frame's table at a time
+                cols_of = {name: [ci for ci, ch in enumerate(self.channel_list) if ch in name] for name in mask_keys}   # analysis.py:96-98, incl. its substring match
                 for f, t in enumerate(self.ts):
                     for (folder, shape), tab in zip(lst, tables):
                         tb = tab[f]
-                        for i, obj in enumerate(tb["ids"]):
-                            d["cell"].append(f"{exp_name}_{chan}_cell{obj}")
-                            d["mask_chan"].append(chan)
-                            d["tag"].append(self.tag)
-                            d["exp"].append(exp_name)
-                            d["frames"].append(f + 1)
-                            d["time"].append(t)
-                            if is_class:                                      # analysis.py:87-92, as written there:
+                        ids = tb["ids"]
+                        n = len(ids)
+                        if not n:
+                            continue
+                        d["cell"].extend([f"{exp_name}_{chan}_cell{obj}" for obj in ids])
+                        d["mask_chan"].extend([chan] * n)
+                        d["tag"].extend([self.tag] * n)
+                        d["exp"].extend([exp_name] * n)
+                        d["frames"].extend([f + 1] * n)
+                        d["time"].extend([t] * n)
+                        if is_class:                                          # analysis.py:87-92, as written there:
+                            for obj in ids:
                                 d["cell_class"].append(f"if cell is {class_keys[1]}")
                                 if obj in pos_lst:                            # an object in neither list gets no entry
                                     d["pos_cell"].append(1)
                                 elif obj in neg_lst:
                                     d["pos_cell"].append(0)
-                            for ci, ch in enumerate(self.channel_list):
-                                for name in mask_keys:
-                                    if ch in name:                       # analysis.py:96-98, incl. its substring match
-                                        d[name].append(tb["mean"][i, ci])
+                        for name, cols in cols_of.items():
+                            if len(cols) == 1:
+                                d[name].extend(tb["mean"][:, cols[0]].tolist())
+                            elif cols:                                        # several channels match: per row, in channel order
+                                d[name].extend(tb["mean"][:, cols].ravel().tolist())
                 df = pd.concat([df, pd.DataFrame.from_dict(d)], ignore_index=True)
             self.df_analysis = type(self).transfo_df(df=df, channel_list=mask_keys, stim_time=stim_time,
                                                      start_baseline=start_baseline, posCont_time=posCont_time,
@@ -606,22 +712,25 @@ class Analysis(Utility):
             for folder, chan, shape in self._mask_sets(maskFold, centroid=True):
                 d = {k: [] for k in keys}
                 tab = self._measure(None, self._label_stack(folder, chan, shape))
-                for f, t in enumerate(self.ts):
+                for f, t in enumerate(self.ts):          # analysis.py:153-173, a frame's table at a time
                     tb = tab[f]
-                    for i, obj in enumerate(tb["ids"]):
-                        d["cell"].append(f"{exp_name}_{chan}_cell{obj}")
-                        d["mask_chan"].append(chan)
-                        d["frames"].append(f + 1)
-                        d["time"].append(t)
-                        d["mask_ID"].append(obj)
-                        c = tb["centroid_rne"][i]
-                        if self.z_size == 1:
-                            d["y"].append(int(c[0]))
-                            d["x"].append(int(c[1]))
-                        else:
-                            d["z"].append(int(c[0]))
-                            d["y"].append(int(c[1]))
-                            d["x"].append(int(c[2]))
+                    ids = tb["ids"]
+                    n = len(ids)
+                    if not n:
+                        continue
+                    d["cell"].extend([f"{exp_name}_{chan}_cell{obj}" for obj in ids])
+                    d["mask_chan"].extend([chan] * n)
+                    d["frames"].extend([f + 1] * n)
+                    d["time"].extend([t] * n)
+                    d["mask_ID"].extend(ids.tolist())
+                    c = tb["centroid_rne"].astype(np.int64)
+                    if self.z_size == 1:
+                        d["y"].extend(c[:, 0].tolist())
+                        d["x"].extend(c[:, 1].tolist())
+                    else:
+                        d["z"].extend(c[:, 0].tolist())
+                        d["y"].extend(c[:, 1].tolist())
+                        d["x"].extend(c[:, 2].tolist())
                 df = pd.concat([df, pd.DataFrame.from_dict(d)], ignore_index=True)
             if not hasattr(self, "df_analysis"):
                 self.df_analysis = pd.DataFrame.from_dict(df)

@@ -95,6 +95,44 @@ def test_pre_process_and_analysis_sequence(dev, tmp_path):
     assert len(b.df_analysis) == len(df)
 
 
+def test_resident_planes_follow_the_files(dev, tmp_path, monkeypatch):
+    """the shim keeps the planes it just wrote on the GPU (smo_bg_sub -> im_reg reads no file), but only while the
+    files still are what it wrote: a plane replaced from outside is read again, and the result is that of a run
+    without the residency"""
+    import time
+    from imageanalysis_pipeline_amd import pipeline as P
+    t, c, y, x = 3, 2, 96, 128
+    chans = ("GFP", "RFP")
+    stack, _ = synth.make_stack(t, c, 1, y, x, n_cells=6, integer_drift=False, seed=9)
+    other, _ = synth.make_stack(1, 1, 1, y, x, n_cells=6, integer_drift=False, seed=77)
+
+    def run(resident_gb, root):
+        monkeypatch.setenv("IAP_SHIM_RESIDENT_GB", resident_gb)
+        P.RESIDENT.clear()
+        exp, _ = make_exp(root, t=t, c=c, y=y, x=x, chans=chans)
+        _write_stack(exp, stack, chans)
+        img = os.path.join(exp, "Images")
+        h0 = P.RESIDENT.hits
+        Utility.smo_bg_sub(imgFold_path=img, sigma=0.0, size=7)
+        Utility.im_reg(img, "GFP", "translation", False, "mean", False)
+        served = P.RESIDENT.hits - h0
+        first = [tiffio.imread(os.path.join(img + "_Registered", "%s_f%04d_z0001.tif" % (ch, f + 1))) for f in range(t) for ch in chans]
+        time.sleep(0.05)
+        tiffio.imwrite(os.path.join(img, "GFP_f0002_z0001.tif"), other[0, 0, 0])      # an external writer
+        Utility.im_reg(img, "GFP", "translation", False, "mean", True)
+        second = [tiffio.imread(os.path.join(img + "_Registered", "%s_f%04d_z0001.tif" % (ch, f + 1))) for f in range(t) for ch in chans]
+        return served, first, second
+
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    served, first, second = run("48", tmp_path / "a")
+    served0, first0, second0 = run("0", tmp_path / "b")
+    assert served == 1 and served0 == 0              # im_reg's read of Images came from the GPU, once
+    assert all(np.array_equal(a, b) for a, b in zip(first, first0))
+    assert all(np.array_equal(a, b) for a, b in zip(second, second0))
+    assert not all(np.array_equal(a, b) for a, b in zip(first, second))   # the replaced plane did change the result
+
+
 def test_man_bg_sub_and_blur(dev, tmp_path):
     exp, stack = make_exp(tmp_path, t=2, c=2, y=40, x=64)
     img = os.path.join(exp, "Images")
