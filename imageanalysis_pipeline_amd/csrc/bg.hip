@@ -873,7 +873,6 @@ static SmoGeom smo_geom(int Y, int X, int band) {
 }
 
 static int pick_band(int Y, int64_t n) {
-  if (const char* e = getenv("IAP_SMO_BAND")) { int b = atoi(e); if (b >= 8) return b; }
   // every band re-primes its 7-row ring (6 rows: 4.7 % at 128 rows, 9 % at 64); ~3072 waves are resident
   // (3 per SIMD), so bands shrink only while fewer than ~4 rounds of waves would be in flight.
   // Measured on C2 (128 planes a launch): 64 rows 14.85, 128 rows 14.26, 256 rows 14.26, 512 rows 15.4 ms/step
@@ -989,7 +988,6 @@ extern "C" int iap_smo_image(const void* in, int in_kind, float* out, int64_t n,
 static int64_t bg_batch_planes(int64_t n, int Y, int X) {
   int64_t per = (int64_t)Y * X * 2;
   int64_t bytes = BG_BATCH_BYTES;
-  if (const char* e = getenv("IAP_BG_BATCH_MB")) { long v = atol(e); if (v > 0) bytes = (int64_t)v << 20; }
   int64_t b = bytes / per;
   if (b < 1) b = 1;
   if (b > 256) b = 256;  // bounds the histogram workspace (257 KiB per plane in flight)

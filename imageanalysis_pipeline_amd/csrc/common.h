@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <stdio.h>
 #include "../../include/iap.h"
 
@@ -46,17 +47,22 @@ enum KernelId {
   K_SMO_MARCH = 0, K_SMO_GENERIC, K_MEDIAN, K_SUB, K_ROWS_R2C, K_COLS, K_ROWS_C2R, K_COARSE, K_UPSAMPLE,
   K_UPFINISH, K_APPLY, K_MEASURE, K_MEASURE_FIN, K_MIP, K_ACCUM, K_GAUSS, K_ROI, K_MAXLABEL, K_OTHER, K_COUNT
 };
-extern bool g_prof_on;
-extern int g_prof_only;   // kernel id the recording is restricted to, -1: every kernel
+// (atomics: host threads may be inside the library at once, each on its own stream; a scope closes the record it
+// opened -- the last open one of its kernel id ON ITS STREAM -- whatever other threads recorded in between)
+extern std::atomic<bool> g_prof_on;
+extern std::atomic<int> g_prof_only;   // kernel id the recording is restricted to, -1: every kernel
 void prof_mark(int kid, hipStream_t st, bool start);
 struct ProfScope {
   int kid;
   hipStream_t st;
+  bool on;
   ProfScope(int k, hipStream_t s) : kid(k), st(s) {
-    if (g_prof_on && (g_prof_only < 0 || g_prof_only == kid)) prof_mark(kid, st, true);
+    const int only = g_prof_only.load(std::memory_order_relaxed);
+    on = g_prof_on.load(std::memory_order_relaxed) && (only < 0 || only == kid);
+    if (on) prof_mark(kid, st, true);
   }
   ~ProfScope() {
-    if (g_prof_on && (g_prof_only < 0 || g_prof_only == kid)) prof_mark(kid, st, false);
+    if (on) prof_mark(kid, st, false);
   }
 };
 

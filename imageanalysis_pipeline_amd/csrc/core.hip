@@ -16,11 +16,12 @@ void set_error(const char* fmt, ...) {
 }  // namespace iap
 
 namespace iap {
-bool g_prof_on = false;
-int g_prof_only = -1;
+std::atomic<bool> g_prof_on{false};
+std::atomic<int> g_prof_only{-1};
 namespace {
 struct ProfRec {
   int kid;
+  hipStream_t st;
   hipEvent_t a, b;
 };
 std::vector<ProfRec> g_recs;
@@ -46,12 +47,12 @@ const char* const k_names[K_COUNT] = {"smo_march_kernel", "smo_generic_kernel", 
 void prof_mark(int kid, hipStream_t st, bool start) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (start) {
-    ProfRec r{kid, take_event(), nullptr};
+    ProfRec r{kid, st, take_event(), nullptr};
     if (r.a) (void)hipEventRecord(r.a, st);
     g_recs.push_back(r);
   } else {
     for (size_t i = g_recs.size(); i-- > 0;) {
-      if (g_recs[i].kid == kid && g_recs[i].b == nullptr) {
+      if (g_recs[i].kid == kid && g_recs[i].st == st && g_recs[i].b == nullptr) {
         g_recs[i].b = take_event();
         if (g_recs[i].b) (void)hipEventRecord(g_recs[i].b, st);
         break;
@@ -68,12 +69,12 @@ extern "C" void iap_prof_enable(int on) {
     if (r.b) iap::g_pool.push_back(r.b);
   }
   iap::g_recs.clear();
-  iap::g_prof_on = on != 0;
+  iap::g_prof_on.store(on != 0);
 }
 
 extern "C" void iap_prof_select(int kernel_id) {
   std::lock_guard<std::mutex> lk(iap::g_prof_mu);
-  iap::g_prof_only = (kernel_id >= 0 && kernel_id < iap::K_COUNT) ? kernel_id : -1;
+  iap::g_prof_only.store((kernel_id >= 0 && kernel_id < iap::K_COUNT) ? kernel_id : -1);
 }
 
 extern "C" int iap_prof_kernel_count(void) { return iap::K_COUNT; }

@@ -158,21 +158,18 @@ __device__ __forceinline__ void dftR(cf* v) {
 // needs no workgroup barrier: the LDS operations of a wave complete in order, the fence only pins the compiler.
 template <int NT>
 __device__ __forceinline__ void fft_sync() {
-#ifndef IAP_FFT_WG_BARRIER
   if constexpr (NT == 64) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-  } else
-#endif
+  } else {
     __syncthreads();
+  }
 }
 
 // After a wave-private FFT, before other waves read its column: the workgroup barrier fft_sync left out.
 template <int NT>
 __device__ __forceinline__ void fft_publish() {
-#ifndef IAP_FFT_WG_BARRIER
   if constexpr (NT == 64) __syncthreads();
-#endif
 }
 
 // One Stockham radix-R pass over an N-point sequence held in LDS (padded index), done by
@@ -968,9 +965,6 @@ __device__ __forceinline__ cf unit_phase(int freq, int ishift, int n, float frac
   return mkc(cs, sn);
 }
 
-#ifdef IAP_UP_STAMPS
-__device__ long long* g_up_stamps;
-#endif
 
 // Ks(t) for t = n + f_j (n integer, f_j = 0.1 (j - 7)), in double.  With alpha = pi n / Py,
 // gamma_j = pi f_j (1 - 1/Py) and delta_j = pi f_j / Py:
@@ -1124,9 +1118,6 @@ __global__ __launch_bounds__(256) void upsample_partial_kernel(const cf* __restr
   __shared__ __align__(16) float Xl[256][16];  // [column]{1, a1..a7, b1..b7, 0}
   __shared__ float red[4][256];
   const int tid = threadIdx.x;
-#ifdef IAP_UP_STAMPS
-  const long long t_start = wall_clock64();
-#endif
   const int cg = blockIdx.x % ncg, uc = blockIdx.x / ncg;
   const int frame = blockIdx.y;
   const int u0 = uc * ub;
@@ -1180,9 +1171,6 @@ __global__ __launch_bounds__(256) void upsample_partial_kernel(const cf* __restr
       r[c][1] = rn[c][1];
     }
   }
-#ifdef IAP_UP_STAMPS
-  const long long t_main = wall_clock64();
-#endif
   // contraction over columns
   const int sy = coarse[frame].x;
   const int wv = tid >> 6, lane = tid & 63, vsub = lane >> 4, blk = lane & 15;
@@ -1245,12 +1233,6 @@ __global__ __launch_bounds__(256) void upsample_partial_kernel(const cf* __restr
     const int j = tid / UP_N, k = tid - j * UP_N;
     part[((size_t)frame * slots + blockIdx.x) * UP_NV + tid] = up_grid_value(&red[0][0], j, k);
   }
-#ifdef IAP_UP_STAMPS
-  if (tid == 0) {
-    long long* o = g_up_stamps + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
-    o[0] = t_start; o[1] = t_main; o[2] = wall_clock64(); o[3] = 0;
-  }
-#endif
 }
 
 // K6 ---------------------------------------------------------------------------------------
@@ -1431,12 +1413,6 @@ constexpr float AP_Z1 = -0.26794919243112270647f;
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 u32x4_px __attribute__((aligned(2)));  // 16-byte load at any pixel address
-#ifdef IAP_AP_STAMPS
-__device__ unsigned long long g_ap_stamps[8];
-#define AP_STAMP(i) do { long long t_ = clock64(); t_acc[i] += t_ - t_last; t_last = t_; } while (0)
-#else
-#define AP_STAMP(i) do {} while (0)
-#endif
 
 struct AxisParams {
   int sh;      // integer part of the source offset: i0 = i + sh
@@ -1521,10 +1497,7 @@ __device__ __forceinline__ int reflect_near(int i, int n) {
   return a;
 }
 
-#ifndef AM_MIN_WAVES
-#define AM_MIN_WAVES 4
-#endif
-__global__ __launch_bounds__(256, AM_MIN_WAVES) void apply_shift_kernel(const uint16_t* __restrict__ in,
+__global__ __launch_bounds__(256, 4) void apply_shift_kernel(const uint16_t* __restrict__ in,
                                                                         uint16_t* __restrict__ out,
                                                                         long long planes_per_frame, int Y, int X,
                                                                         const double* __restrict__ shifts, int nty,
@@ -1538,9 +1511,6 @@ __global__ __launch_bounds__(256, AM_MIN_WAVES) void apply_shift_kernel(const ui
   __shared__ __align__(16) v2f colp[(AP_TX / 2) * AM_CP];   // x-filtered rows: [column pair (c, c+32)][row]
   __shared__ AxisParams pay, pax;
   const int tid = threadIdx.x;
-#ifdef IAP_AP_STAMPS
-  long long t_last = clock64(), t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
   const long long plane = blockIdx.z;
   const long long frame = plane / planes_per_frame;
   // background level subtracted as the samples are staged (two pixels per saturating packed subtract); 0 without sub2
@@ -1691,23 +1661,18 @@ __global__ __launch_bounds__(256, AM_MIN_WAVES) void apply_shift_kernel(const ui
     stage(src0 + AM_HALO);
     if (ty0 + 1 < ty1 && wide) preload(src0 + AM_HALO + AM_TY);
   }
-  AP_STAMP(0);
 
   for (int ty = ty0; ty < ty1; ++ty) {
     const int oy = ty * AM_TY;
     const int nsrc = oy + AM_TY + ay.sh + AP_R + 2;   // first new source row of the next step
     const bool more = ty + 1 < ty1;
     __syncthreads();   // A: staged rows and the carried rows are visible; colp rows 25.. are free
-    AP_STAMP(1);
     xpass(AM_TY, AM_HALO);
-    AP_STAMP(2);
     __syncthreads();   // B: colp is complete, the tile is free
-    AP_STAMP(3);
     if (more) stage(nsrc);
     // the loads of the step after that fly during this y pass and the next x pass; they are older than
     // the stores below, so waiting for them (vmcnt counts in order) does not wait for a store
     if (ty + 2 < ty1 && wide) preload(nsrc + AM_TY);
-    AP_STAMP(4);
     // ---- y pass: a column pair per lane, 8 rows per thread; stores go straight to the plane
     {
       const int pr = tid & 31, y0 = (tid >> 5) * AM_G;
@@ -1735,9 +1700,6 @@ __global__ __launch_bounds__(256, AM_MIN_WAVES) void apply_shift_kernel(const ui
         unsigned* o0 = reinterpret_cast<unsigned*>(po + (size_t)(oy + y0) * X + xa);
 #pragma unroll
         for (int k = 0; k < AM_G; ++k) {   // clamp, then truncation toward zero; written once, not re-read here
-#ifdef AP_X_NOSTORE
-          if (res[k].x != 1.2345e-30f) continue;
-#endif
           const unsigned a = (unsigned)__builtin_amdgcn_fmed3f(res[k].x, 0.f, 65535.f);
           const unsigned b = (unsigned)__builtin_amdgcn_fmed3f(res[k].y, 0.f, 65535.f);
           __builtin_nontemporal_store(a | (b << 16), o0 + (size_t)k * (X >> 1));
@@ -1761,7 +1723,6 @@ __global__ __launch_bounds__(256, AM_MIN_WAVES) void apply_shift_kernel(const ui
         }
       }
     }
-    AP_STAMP(5);
     if (more) {
       __syncthreads();   // C: the y pass has read colp; carry rows 64..89 up to rows 0..25
       for (int i = tid; i < (AP_TX / 2) * 13; i += 256) {
@@ -1770,12 +1731,7 @@ __global__ __launch_bounds__(256, AM_MIN_WAVES) void apply_shift_kernel(const ui
         c[k] = c[AM_TY / 2 + k];
       }
     }
-    AP_STAMP(6);
   }
-#ifdef IAP_AP_STAMPS
-  if (tid == 0)
-    for (int i = 0; i < 7; ++i) atomicAdd(&g_ap_stamps[i], (unsigned long long)t_acc[i]);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2142,10 +2098,7 @@ static int launch_apply(const uint16_t* in, uint16_t* out, long long n_frames, l
   // each workgroup walks `nty` steps down its strip.  Long walks amortise the 25-row lead-in, short ones keep
   // neighbouring strips close enough in time for the columns they share to be served by L2: 8 measured best
   int nty = 8;
-  const char* e = getenv("IAP_APPLY_NTY");   // experiments and tests: taken as given
-  if (e && atoi(e) > 0) nty = atoi(e);
-  else
-    while (nty > 1 && (long long)tiles_x * ((tiles_y + nty - 1) / nty) * ppf * n_frames < 2048) nty >>= 1;
+  while (nty > 1 && (long long)tiles_x * ((tiles_y + nty - 1) / nty) * ppf * n_frames < 2048) nty >>= 1;
   dim3 grid(tiles_x, (tiles_y + nty - 1) / nty, 1);
   // blockIdx.z is limited to 65535: chunk by whole frames
   long long fpc = 65535 / ppf;
@@ -2166,13 +2119,6 @@ static int launch_apply(const uint16_t* in, uint16_t* out, long long n_frames, l
 
 using namespace iap;
 
-#ifdef IAP_AP_STAMPS
-extern "C" void iap_debug_ap_stamps(unsigned long long* host8) {
-  (void)hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_ap_stamps), 8 * sizeof(unsigned long long));
-  unsigned long long z[8] = {0};
-  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ap_stamps), z, sizeof(z));
-}
-#endif
 
 extern "C" int iap_mip_u16(const uint16_t* in, int64_t in_stride, uint16_t* out, int64_t n, int Z, int Y, int X,
                            void* stream) {

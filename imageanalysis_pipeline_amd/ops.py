@@ -56,7 +56,14 @@ def max_label(labels: torch.Tensor) -> int:
     return int(out.item())
 
 
-PROVISIONAL_LABELS = 8192   # accumulator rows of a measurement whose label range is not known beforehand
+PROVISIONAL_LABELS = 8192   # accumulator rows of a measurement whose label range is not known beforehand ...
+PROVISIONAL_BYTES = 256 << 20   # ... as far as T frames of them fit this many bytes (never fewer than 256 rows)
+
+
+def provisional_labels(t: int, c: int) -> int:
+    """Rows of the provisional table of a T-frame, C-channel measurement: T x rows x (4+C) int64 stays within
+    PROVISIONAL_BYTES (T=5000, C=3 would otherwise hold 2.3 GB for masks of a few hundred ids)."""
+    return int(min(PROVISIONAL_LABELS, max(256, PROVISIONAL_BYTES // (max(t, 1) * (4 + c) * 8))))
 
 
 def _measure_call(img, labels, L, acc, frame_max=None):
@@ -75,7 +82,8 @@ def measure_accumulate(img: torch.Tensor, labels: torch.Tensor, n_labels: int | 
     int64 (T, L, 4+C): count, sum_z, sum_y, sum_x, sum_I[c]  (analysis.py:80-98,164-173).
     L = ``n_labels`` or, when that is not given, largest label + 1 (the reference's np.unique(mask) range): the
     measuring pass itself reports the largest label, so the label stack is not read a second time for it; only a
-    stack with more than PROVISIONAL_LABELS ids is measured again with the range it turned out to need."""
+    stack with more ids than the provisional table holds (``provisional_labels``) is measured again with the range
+    it turned out to need."""
     _need_cuda(img, labels)
     _u16(img)
     _u16(labels)
@@ -88,11 +96,12 @@ def measure_accumulate(img: torch.Tensor, labels: torch.Tensor, n_labels: int | 
         acc = torch.empty((t, int(n_labels), 4 + c), dtype=torch.int64, device=img.device)
         _measure_call(img, labels, int(n_labels), acc)
         return acc
-    acc = torch.empty((t, PROVISIONAL_LABELS, 4 + c), dtype=torch.int64, device=img.device)
+    L0 = provisional_labels(t, c)
+    acc = torch.empty((t, L0, 4 + c), dtype=torch.int64, device=img.device)
     fmax = torch.empty(t, dtype=torch.int32, device=img.device)
-    _measure_call(img, labels, PROVISIONAL_LABELS, acc, fmax)
+    _measure_call(img, labels, L0, acc, fmax)
     L = int(fmax.max().item()) + 1
-    if L > PROVISIONAL_LABELS:
+    if L > L0:
         acc = torch.empty((t, L, 4 + c), dtype=torch.int64, device=img.device)
         _measure_call(img, labels, L, acc)
         return acc
@@ -523,10 +532,11 @@ def hot_path(stack: torch.Tensor, labels: torch.Tensor, threshold: float, reg_ch
     if n_labels is not None:
         return measure_finalize(blocks(int(n_labels), None)), shifts, levels
     fmax = torch.empty(t, dtype=torch.int32, device=stack.device)
-    acc = blocks(PROVISIONAL_LABELS, fmax)
+    L0 = provisional_labels(t, c)
+    acc = blocks(L0, fmax)
     L = int(fmax.max().item()) + 1
     # more ids than the provisional table holds: the blocks are warped and measured once more (as rare as such masks)
-    acc = blocks(L, None) if L > PROVISIONAL_LABELS else acc[:, :L].contiguous()
+    acc = blocks(L, None) if L > L0 else acc[:, :L].contiguous()
     return measure_finalize(acc), shifts, levels
 
 

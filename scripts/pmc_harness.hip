@@ -9,7 +9,6 @@
 //   pmc_harness smosigma <planes> [Y X]         iap_bg_smo_u16 with SMO's gaussian pre-filter, sigma 1 (levels only)
 // Prints the mean wall time per call (HIP events) so a run without the profiler doubles as a micro-benchmark.
 #include <hip/hip_runtime.h>
-#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -188,23 +187,6 @@ int main(int argc, char** argv) {
   }
   CK(hipEventSynchronize(e1));
   CK(hipEventElapsedTime(&ms, e0, e1));
-  // development builds of the library (-DIAP_COL_STAMPS) export per-phase cycle sums of the column kernel
-  if (void* fn = dlsym(RTLD_DEFAULT, "iap_debug_col_stamps")) {
-    unsigned long long st[16];
-    ((void (*)(unsigned long long*))fn)(st);
-    fprintf(stderr, "col stamps (cycles per workgroup, %llu workgroups):", st[15]);
-    for (int i = 0; i < 10; ++i) fprintf(stderr, " %.0f", st[15] ? (double)st[i] / (double)st[15] : 0.0);
-    fprintf(stderr, "\n");
-  }
-  if (void* fn = dlsym(RTLD_DEFAULT, "iap_debug_ap_stamps")) {   // -DIAP_AP_STAMPS: phases of the warp kernel
-    unsigned long long st[8];
-    ((void (*)(unsigned long long*))fn)(st);
-    double tot = 0;
-    for (int i = 0; i < 7; ++i) tot += (double)st[i];
-    fprintf(stderr, "apply stamps (share of thread 0's cycles: lead-in, wait A, x pass, wait B, stage+prefetch, y pass, wait C+carry):");
-    for (int i = 0; i < 7; ++i) fprintf(stderr, " %.3f", tot > 0 ? (double)st[i] / tot : 0.0);
-    fprintf(stderr, "\n");
-  }
   printf("{\"stage\": \"%s\", \"n\": %lld, \"C\": %d, \"Y\": %d, \"X\": %d, \"dense\": %d, \"ms_per_call\": %.4f, \"reps\": %d}\n",
          stage, n, C, Y, X, dense, ms / reps, reps);
   return 0;

@@ -135,15 +135,36 @@ def test_apply_fractional_shifts(dev):
     _check_apply(img, [(0.3, -1.7), (-2.5, 0.25), (0.0, 0.5), (10.2, 0.0), (-0.999, 0.001), (35.5, -64.25)], dev)
 
 
-@pytest.mark.parametrize("nty", [1, 2, 3, 8])
-def test_apply_marching_steps(dev, nty, monkeypatch):
+@pytest.mark.parametrize("planes,steps", [(1, 1), (25, 2), (37, 4), (74, 8)])
+def test_apply_marching_steps(dev, planes, steps):
     """the workgroup's walk down a 64-column strip: several 64-row steps per workgroup (carried x-filtered
-    rows), ragged last step and last strip, walks that start or end outside the image, whole-pixel axes"""
-    monkeypatch.setenv("IAP_APPLY_NTY", str(nty))
-    rng = np.random.default_rng(20 + nty)
-    img = rng.integers(0, 65536, size=(7, 1, 1, 333, 200)).astype(np.uint16)
-    _check_apply(img, [(0.3, -1.7), (-70.5, 0.25), (130.25, -3.0), (-4.0, 66.6), (5.0, -9.0), (-332.5, 0.5),
-                       (400.0, 0.5)], dev)
+    rows), ragged last step and last strip, walks that start or end outside the image, whole-pixel axes.  The
+    library picks the steps per walk from the size of the launch (8 once 2048 workgroups are there): 7 frames of
+    `planes` planes of 333 x 200 give walks of 1, 2, 4 and 8 steps (6 row tiles: the last walk is ragged)."""
+    tiles_x, tiles_y = 4, 6
+    nty = 8
+    while nty > 1 and tiles_x * -(-tiles_y // nty) * planes * 7 < 2048:
+        nty //= 2
+    assert nty == steps                                  # the test's premise (launch_apply's rule)
+    from imageanalysis_pipeline_amd import ops
+    rng = np.random.default_rng(20 + steps)
+    two = rng.integers(0, 65536, size=(7, 2, 1, 333, 200)).astype(np.uint16)
+    shifts = [(0.3, -1.7), (-70.5, 0.25), (130.25, -3.0), (-4.0, 66.6), (5.0, -9.0), (-332.5, 0.5), (400.0, 0.5)]
+    _check_apply(two, shifts, dev) if planes == 1 else None
+    # `planes` planes per frame: copies of plane 0, the last one different; the first and the last against the
+    # oracle, the copies against the first (bit for bit)
+    img = np.repeat(two[:, :1], planes, axis=1)
+    img[:, -1] = two[:, 1]
+    got = ops.to_numpy_u16(ops.apply_shifts(ops.to_device_u16(img, dev), torch.tensor(shifts, dtype=torch.float64, device=dev)))
+    for f, (dy, dx) in enumerate(shifts):
+        for k in {0, planes - 1}:
+            exp = O.apply_shift(img[f, k, 0], dy, dx)
+            if float(dy).is_integer() and float(dx).is_integer():
+                assert np.array_equal(got[f, k, 0], exp), (f, k)
+            else:
+                assert np.abs(got[f, k, 0].astype(np.int64) - exp.astype(np.int64)).max() <= WARP_TOL, (f, k)
+        for k in range(1, planes - 1):
+            assert np.array_equal(got[f, k], got[f, 0]), (f, k)
 
 
 @pytest.mark.parametrize("shape", [(8, 6), (33, 17), (5, 70), (64, 64), (65, 129)])
