@@ -1489,6 +1489,13 @@ __device__ __forceinline__ void spline_run2(F s, M mid, const float (&w)[4], v2f
   }
 }
 
+// float -> u32, truncating toward zero, negatives to 0 (the instruction's own clamp; a C cast leaves them undefined)
+__device__ __forceinline__ unsigned cvt_u32_floor0(float v) {
+  unsigned r;
+  asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+
 // mirror index for the common single reflection, the general form otherwise
 __device__ __forceinline__ int reflect_near(int i, int n) {
   int a = i < 0 ? -i : i;
@@ -1697,12 +1704,22 @@ __global__ __launch_bounds__(256, 4) void apply_shift_kernel(const uint16_t* __r
       const bool interior = ox >= ax.lo && ox + AP_TX - 1 <= ax.hi && oy >= ay.lo && oy + AM_TY - 1 <= ay.hi &&
                             ox + AP_TX <= X && oy + AM_TY <= Y && pair_store;
       if (interior) {   // uniform: every output has its source inside the image and lies inside the plane
-        unsigned* o0 = reinterpret_cast<unsigned*>(po + (size_t)(oy + y0) * X + xa);
+        // a row's address = a wave-uniform base (scalar arithmetic) + this lane's fixed 32-bit offset
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const size_t rowb = ((size_t)(oy + 2 * AM_G * wv) * X + ox) * 2;
+        const unsigned lane_off = (unsigned)(((tid >> 5) & 1) * AM_G * X + 2 * pr) * 2u;
 #pragma unroll
-        for (int k = 0; k < AM_G; ++k) {   // clamp, then truncation toward zero; written once, not re-read here
-          const unsigned a = (unsigned)__builtin_amdgcn_fmed3f(res[k].x, 0.f, 65535.f);
-          const unsigned b = (unsigned)__builtin_amdgcn_fmed3f(res[k].y, 0.f, 65535.f);
-          __builtin_nontemporal_store(a | (b << 16), o0 + (size_t)k * (X >> 1));
+        for (int k = 0; k < AM_G; ++k) {   // truncation toward zero and the clamp to 0 .. 65535 ride in the two conversions
+          // (v_cvt_u32_f32 sends negatives to 0, v_cvt_pk_u16_u32 saturates at 65535); written once, not re-read here
+          typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+          const us2 ab = __builtin_amdgcn_cvt_pk_u16(cvt_u32_floor0(res[k].x), cvt_u32_floor0(res[k].y));
+          typedef __attribute__((address_space(1))) char gchar;
+          typedef __attribute__((address_space(1))) unsigned gu32;
+          gchar* rk = (gchar*)(reinterpret_cast<char*>(po) + rowb + (size_t)k * X * 2);
+          asm("" : "+s"(rk));   // stays a scalar base: the store then takes base + 32-bit lane offset, no vector address arithmetic
+          unsigned lo = lane_off;
+          asm("" : "+v"(lo));   // (kept 32 bits wide up to the store)
+          __builtin_nontemporal_store(__builtin_bit_cast(unsigned, ab), (gu32*)(rk + lo));
         }
       } else {
         const bool ain = xa >= ax.lo && xa <= ax.hi, bin = xb >= ax.lo && xb <= ax.hi;
