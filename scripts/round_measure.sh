@@ -9,7 +9,7 @@ timeout -k 10 500 python -u bench.py --stage-report > $out/c2_bench.json 2> $out
 echo c2 done
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/c2_prof -o c2 --output-format csv -- python3 bench.py --no-traffic --no-cpu-baseline --no-verify > $out/c2_bench_under_rocprof.json 2> $out/c2_prof.err || exit 1
 echo c2 rocprof done
-for w in c1 c4fov c5 c3; do
+for w in c1 c4fov c5 c3 blur smosigma; do
   timeout -k 10 600 python -u bench.py --workload $w --stage-report > $out/${w}_bench.json 2> $out/${w}_bench.err || { tail -5 $out/${w}_bench.err; exit 1; }
   echo $w done
 done
