@@ -1402,9 +1402,9 @@ __global__ __launch_bounds__(256) void accum_planes_kernel(const uint16_t* __res
 //
 // A workgroup owns a strip of 64 output columns and walks down it 64 rows a step.  The x-filtered
 // rows the next step needs again (2R+3 = 25) stay in LDS, so every source row is staged and
-// x-filtered once per strip.  Both passes work on packed f32 pairs (v_pk_fma_f32 issues at the
-// rate of v_fma_f32 here): a thread runs the columns c and c+32 together, which halves the FMA
-// issue count -- the tile kernel this replaces was bound by VALU issue, not by HBM.
+// x-filtered once per strip.  Both passes work on packed f32 pairs: a thread runs the columns c and
+// c+32 together, which halves the instruction count (not the arithmetic time: per SIMD a
+// v_pk_fma_f32 costs two v_fma_f32 at 4 waves, scripts/chainbench.hip) and the per-run bookkeeping.
 constexpr int AP_R = 11;
 constexpr int AP_TX = 64;      // output columns per strip
 constexpr int AP_TW = 96;      // staged columns, starting at the first sample the strip needs: 12 u16x8 vectors
