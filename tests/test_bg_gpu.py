@@ -181,6 +181,35 @@ def test_gauss_blur_bit_exact(dev, k, sig):
         ops.gauss_blur(ops.to_device_u16(img, dev), [15, 15], 5.0)
 
 
+@pytest.mark.parametrize("r", [1, 2, 3, 4, 5, 6, 7])
+def test_gauss_blur_marching_kernel_bit_exact(dev, r):
+    """Square kernels of radius 1..7 on planes of even width take the marching kernel (128-column strips, 32-row steps,
+    bands of up to 256 rows): planes narrower than a strip, a column past a strip, more rows than a band, fewer rows and
+    columns than the kernel's reach (cv2's BORDER_REFLECT_101 folds more than once), sigma given and derived from the
+    size."""
+    from imageanalysis_pipeline_amd import ops
+    rng = np.random.default_rng(100 + r)
+    k = 2 * r + 1
+    for shape, sig in (((2, 64, 64), 0.0), ((1, 301, 258), 1.3), ((3, 33, 130), 0.0), ((1, 5, 8), 2.0),
+                       ((1, 2, 300), 0.7), ((1, 530, 16), 5.0)):
+        img = rng.integers(0, 65536, size=shape).astype(np.uint16)
+        if shape[1] > 300:
+            img[:, :40] = 65535       # saturated and empty stretches: rounding at the ends of the range
+            img[:, 40:80] = 0
+        got = ops.to_numpy_u16(ops.gauss_blur(ops.to_device_u16(img, dev), (k, k), sig))
+        for i in range(shape[0]):
+            assert np.array_equal(got[i], O.gauss_blur(img[i], (k, k), sig)), (shape, sig, i)
+
+
+def test_gauss_blur_marching_kernel_full_plane(dev):
+    """The reference's default (15, 15), sigma 5 (experiments.py:337) on 2048 x 2048 planes: 16 strips x 8 bands."""
+    from imageanalysis_pipeline_amd import ops
+    img = _frames(2, 2048, 2048, seed=21)
+    got = ops.to_numpy_u16(ops.gauss_blur(ops.to_device_u16(img, dev), (15, 15), 5.0))
+    for i in range(2):
+        assert np.array_equal(got[i], O.gauss_blur(img[i], (15, 15), 5.0))
+
+
 def test_smo_image_and_threshold_with_sigma(dev):
     """SMO(sigma > 0): gaussian pre-smoothing (scipy 'reflect', truncate 4) ahead of the operator, for the
     image planes and for the null image the threshold comes from (utility.py:252)."""
@@ -195,3 +224,17 @@ def test_smo_image_and_threshold_with_sigma(dev):
     e = O.smo_threshold((128, 256), sigma=1.5, seed=0)
     assert abs(t - e) <= 2e-5 * e + 2e-6
     assert t != ops.smo_threshold((128, 256), sigma=0.0, seed=0, device=dev)
+
+
+@pytest.mark.parametrize("sigma", [0.6, 3.0, 7.5, 9.0])
+def test_smo_sigma_prefilter_paths(dev, sigma):
+    """The gaussian pre-filter of SMO(sigma > 0) (scipy 'reflect', truncate 4): radii up to 31 go through the LDS tile
+    kernel, larger ones (sigma 9: radius 36) through the two-pass form; planes smaller than the filter's reach and
+    planes that are not a multiple of the tile included."""
+    from imageanalysis_pipeline_amd import ops
+    for y, x in ((50, 70), (200, 312), (19, 40)):
+        img = _frames(1, y, x, seed=int(10 * sigma) + y)
+        got = ops.smo_image(ops.to_device_u16(img, dev), 7, sigma=sigma).cpu().numpy()[0]
+        exp = O.smo_image(img[0].astype(np.float64), sigma, 7)
+        # as test_smo_image_and_threshold_with_sigma: fp32 smoothed plane, differences of neighbours a count apart
+        assert np.quantile(np.abs(got - exp), 0.999) <= 3e-4, (sigma, y, x, np.abs(got - exp).max())
