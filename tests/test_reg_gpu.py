@@ -184,9 +184,11 @@ def test_apply_saturation_and_negative_clip(dev):
 
 @pytest.mark.parametrize("mode", ["first", "mean", "previous"])
 @pytest.mark.parametrize("integer", [True, False])
-def test_im_reg_modes(dev, mode, integer):
+@pytest.mark.parametrize("plane", [(128, 192), (256, 320)])
+def test_im_reg_modes(dev, mode, integer, plane):
+    """(windows below 256 points keep their spectra as float pairs, 256 and up as half pairs: both storage forms)"""
     from imageanalysis_pipeline_amd import ops
-    st, _ = _stack(5, 2, 1, 128, 192, integer, seed=11)
+    st, _ = _stack(5, 2, 1, plane[0], plane[1], integer, seed=11)
     out, sh = ops.im_reg(ops.to_device_u16(st, dev), reg_channel=1, reg_ref=mode, upsample=not integer, batch=2)
     eo, es = O.im_reg_stack(st, reg_channel=1, reg_ref=mode, upsample=not integer)
     sh = sh.cpu().numpy()
@@ -209,13 +211,14 @@ def test_im_reg_previous_same_for_every_batch(dev):
     pass runs ahead (batch 1: not at all, the reference spectrum goes through its own launches).  Shifts
     and planes do not depend on it, bit for bit."""
     from imageanalysis_pipeline_amd import ops
-    st, _ = _stack(7, 2, 1, 128, 192, False, seed=23)
-    d = ops.to_device_u16(st, dev)
-    ref_out, ref_sh = ops.im_reg(d, reg_channel=0, reg_ref="previous", upsample=True, batch=1)
-    for batch in (2, 3, 16):
-        out, sh = ops.im_reg(d, reg_channel=0, reg_ref="previous", upsample=True, batch=batch)
-        assert torch.equal(sh, ref_sh), batch
-        assert torch.equal(out.view(torch.int16), ref_out.view(torch.int16)), batch
+    for y, x in ((128, 192), (256, 256)):   # float-pair and half-pair spectra
+        st, _ = _stack(7, 2, 1, y, x, False, seed=23)
+        d = ops.to_device_u16(st, dev)
+        ref_out, ref_sh = ops.im_reg(d, reg_channel=0, reg_ref="previous", upsample=True, batch=1)
+        for batch in (2, 3, 16):
+            out, sh = ops.im_reg(d, reg_channel=0, reg_ref="previous", upsample=True, batch=batch)
+            assert torch.equal(sh, ref_sh), (y, x, batch)
+            assert torch.equal(out.view(torch.int16), ref_out.view(torch.int16)), (y, x, batch)
 
 
 @pytest.mark.parametrize("mode", ["first", "mean", "previous"])
