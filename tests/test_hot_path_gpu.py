@@ -239,3 +239,66 @@ def test_two_host_threads_give_the_same_bits(dev):
         assert torch.equal(g[1], r[1]) and torch.equal(g[2], r[2])
         for a, b in zip(g[0], r[0]):
             assert torch.equal(a, b)
+
+
+def test_profiling_pairs_events_per_stream(dev):
+    """iap_prof_* with two host threads launching the same kernels on their own streams: a scope closes the record
+    it opened on ITS stream, so every launch is counted once and every duration is that of one launch (a record
+    paired across streams would carry an event of the other thread's stream: negative, or as long as the other
+    thread's whole backlog)."""
+    import ctypes
+    import threading
+    from imageanalysis_pipeline_amd import _lib
+    lib = _lib.load()
+    t, c, y, x = 4, 2, 128, 192
+    st, _ = synth.make_stack(t, c, 1, y, x, n_cells=9, integer_drift=False, seed=41)
+    d, dl = ops.to_device_u16(st, dev), ops.to_device_u16(_labels(t, 1, y, x, 6, seed=41), dev)
+    ops.hot_path(d, dl, THR, reg_ref="mean")          # workspaces of the default stream allocated, tables warm
+    torch.cuda.synchronize()
+    names = [lib.iap_prof_kernel_name(k).decode() for k in range(lib.iap_prof_kernel_count())]
+
+    def collect():
+        out = {}
+        for k, nm in enumerate(names):
+            ms, n = ctypes.c_double(0), ctypes.c_int64(0)
+            assert lib.iap_prof_collect(k, ctypes.byref(ms), ctypes.byref(n)) == 0
+            if n.value:
+                out[nm] = (ms.value, n.value)
+        return out
+
+    lib.iap_prof_select(-1)
+    lib.iap_prof_enable(1)
+    ops.hot_path(d, dl, THR, reg_ref="mean")
+    torch.cuda.synchronize()
+    one = collect()
+    lib.iap_prof_enable(0)
+    assert one and all(ms > 0 for ms, _ in one.values())
+
+    rounds, nthreads = 3, 3
+    errs = []
+
+    def work():
+        try:
+            s = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(s):
+                for _ in range(rounds):
+                    ops.hot_path(d, dl, THR, reg_ref="mean")
+            s.synchronize()
+        except Exception as e:            # noqa: BLE001
+            errs.append(repr(e))
+
+    lib.iap_prof_enable(1)
+    threads = [threading.Thread(target=work) for _ in range(nthreads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    torch.cuda.synchronize()
+    many = collect()
+    lib.iap_prof_enable(0)
+    assert not errs, errs
+    assert set(many) == set(one)
+    for nm, (ms, n) in many.items():
+        assert n == one[nm][1] * rounds * nthreads, (nm, n, one[nm])
+        # per launch: positive, and not the length of another stream's backlog (generous: the streams share the GPU)
+        assert 0 < ms / n < 50 * max(one[nm][0] / one[nm][1], 0.02), (nm, ms, n, one[nm])
