@@ -309,12 +309,20 @@ __device__ __forceinline__ void fft_inv_regs(cf* s, int j, const cf* __restrict_
   fft_rec<N, E, +1, R>(s, j, tw);
 }
 
+// Columns per workgroup of the column kernels, for N-point columns.  4 columns x 8 (4) rows of the row-interleaved
+// spectra are one 128-byte line, so 4 is the smallest tile that moves whole lines; larger tiles mean fewer, bigger
+// workgroups.  Measured per size (round 3, scripts/pmc_harness estimate): 2048 points 4 (74 KB of LDS per tile as it
+// is); 1024 points 8 (4: +5 %); 512 points 4 (16: +10 %; a 512 x 512 frame is 65 tiles instead of 17, which is
+// also what a single-frame launch of the serial chain lives on); 256 points no difference between 4, 8 and 16;
+// 128 points 8 (16: +2.5 %).
+constexpr int col_tile(int N) { return N >= 2048 ? 4 : (N == 1024 ? 8 : (N >= 256 ? 4 : 8)); }
+
 template <int N>
 struct FftGeom {
   static constexpr int NT = N / 8;                            // threads per FFT
   static constexpr int PADN = N + N / 8;                      // padded LDS points per FFT
   static constexpr int G = (256 / NT) > 1 ? (256 / NT) : 1;   // row FFTs per workgroup
-  static constexpr int TC = (8192 / N) < 16 ? (8192 / N) : 16;  // columns per workgroup
+  static constexpr int TC = col_tile(N);                      // columns per workgroup
   static constexpr int CE = N >= 128 ? 16 : 8;                // points per thread in the column kernels
   static constexpr int CNT = N / CE;                          // threads per column FFT
   static constexpr int CWPS = 4;                              // waves per SIMD the column kernels are compiled for (LDS allows no more)
@@ -1776,7 +1784,7 @@ static int geom_rows_RPQ(int N) {
   int g = 256 / nt;
   return g > 2 ? g : 2;
 }
-static int geom_TC(int N) { return (8192 / N) < 16 ? (8192 / N) : 16; }
+static int geom_TC(int N) { return col_tile(N); }
 
 static bool make_plan(int Y, int X, RegPlan& p) {
   p.Y = Y;
