@@ -8,13 +8,14 @@
 //
 // Kernel shape (HBM-bound, 2 + 2/C algorithmic bytes per stack pixel):
 //   grid = (chunks per frame, T); one 256-thread workgroup owns CHUNK consecutive pixels of
-//   the flattened (z,y,x) index space of one frame.  Each lane loads 8 labels (16 B) and
-//   8 pixels per channel (only where at least one of the 8 labels is non-zero: background-only vectors skip
-//   the image loads altogether), run-length-aggregates equal neighbouring labels in registers and
-//   adds the run to an open-addressing hash table in LDS (ds_add_u32); the table is flushed
-//   with one 64-bit global atomic per (label, field) per workgroup.  Label 0 (background,
-//   the bulk of the pixels) never touches the table: it is counted per lane and reduced
-//   with wave shuffles.
+//   the flattened (z,y,x) index space of one frame.  Each lane loads its 8 x 8 labels (16 B at a time, all
+//   requested at once); vectors of eight background pixels are only counted (their image pixels are never
+//   loaded), the others are queued in LDS and then visited by all lanes, one vector each (a round of a wave in
+//   which half the lanes hold a labelled vector is visited in place: dense masks): 8 pixels per channel,
+//   run-length aggregation of equal neighbouring labels in registers, the run added to an open-addressing hash
+//   table in LDS (ds_add_u32); the table is flushed with one 64-bit global atomic per (label, field) per
+//   workgroup.  Label 0 (background, the bulk of the pixels) never touches the table: it is counted per lane and
+//   reduced with wave shuffles.
 #include "common.h"
 
 namespace iap {
@@ -23,6 +24,7 @@ constexpr int MEAS_THREADS = 256;
 constexpr int MEAS_ITERS = 8;
 constexpr int MEAS_HASH_LOG2 = 9;
 constexpr int MEAS_HASH = 1 << MEAS_HASH_LOG2;  // slots per workgroup
+constexpr int MEAS_DIRECT = 32;   // labelled vectors in a wave's round from which the round is visited in place (16 .. 48: no difference)
 
 template <int NC>
 struct MeasTable {
@@ -34,6 +36,8 @@ struct MeasTable {
   unsigned si[NC][MEAS_HASH];
   unsigned bg;
   unsigned mx;   // largest label the workgroup saw (only kept when the caller asks for the frame maxima)
+  unsigned qn;   // queued vectors
+  unsigned short queue[MEAS_THREADS * MEAS_ITERS];   // label-carrying vectors of the chunk (index within the chunk)
 };
 
 template <int NC, bool COORDS>
@@ -97,6 +101,7 @@ __global__ __launch_bounds__(MEAS_THREADS) void measure_kernel(
   if (tid == 0) {
     tb.bg = 0;
     tb.mx = 0;
+    tb.qn = 0;
   }
   __syncthreads();
 
@@ -108,23 +113,12 @@ __global__ __launch_bounds__(MEAS_THREADS) void measure_kernel(
   const unsigned yx = (unsigned)Y * (unsigned)X;
   unsigned bg = 0, mx = 0;
 
-#pragma unroll 2
-  for (int it = 0; it < MEAS_ITERS; ++it) {
-    unsigned p = chunk0 + (it * MEAS_THREADS + tid) * VEC;
-    if (p >= zyx) break;
+  // One vector (VEC pixels from flat index p on) into the table: image loads, run-length aggregation, table adds.
+  auto visit = [&](unsigned p) {
     uint16_t lv[VEC];
     uint16_t iv[NC][VEC];
     if (VEC == 8) {
-      u16x8 l8 = load8_nt(lab_f + p);
-      {  // eight background pixels: nothing of the image is needed for them, so it is not loaded either -- on
-         // sparse masks (C2: 2.5 % of the pixels carry a label) most image lines are never fetched
-        iap_u32x4 lw;
-        __builtin_memcpy(&lw, &l8, 16);
-        if ((lw.x | lw.y | lw.z | lw.w) == 0u) {
-          bg += 8;
-          continue;
-        }
-      }
+      u16x8 l8 = load8(lab_f + p);   // (again: a cache hit, and only for the vectors with a label)
 #pragma unroll
       for (int i = 0; i < 8; ++i) lv[i] = l8.v[i];
       if (frame_max) {
@@ -177,6 +171,61 @@ __global__ __launch_bounds__(MEAS_THREADS) void measure_kernel(
       }
     }
     meas_flush_run<NC, COORDS>(tb, cur, cnt, sz, sy, sx, si, L, acc_f, F, c0, bg);
+  };
+
+  if (VEC == 8) {
+    // The lane's label vectors of the whole chunk are requested at once (MEAS_ITERS 16-byte loads in flight per
+    // lane).  Eight background pixels need nothing of the image, so it is not loaded either -- on sparse masks
+    // (C2: 2.5 % of the pixels carry a label) most image lines are never fetched.  The vectors that do carry a
+    // label are queued in LDS and visited afterwards by ALL lanes, one vector each: the label-carrying vectors
+    // cluster (a blob covers two or three neighbouring lanes of a wave), and visiting them where they were found
+    // ran the long path -- dependent image loads, eight steps of run-length bookkeeping, table atomics -- with two
+    // or three lanes of a wave active, once per round of almost every wave.
+    unsigned todo = 0;       // bit `it`: the lane's vector of round `it` carries a label
+    {
+      u16x8 l8[MEAS_ITERS];
+#pragma unroll
+      for (int it = 0; it < MEAS_ITERS; ++it) {
+        const unsigned p = chunk0 + (it * MEAS_THREADS + tid) * VEC;
+        if (p < zyx) l8[it] = load8(lab_f + p);
+      }
+#pragma unroll
+      for (int it = 0; it < MEAS_ITERS; ++it) {
+        const unsigned p = chunk0 + (it * MEAS_THREADS + tid) * VEC;
+        if (p < zyx) {
+          iap_u32x4 lw;
+          __builtin_memcpy(&lw, &l8[it], 16);
+          if ((lw.x | lw.y | lw.z | lw.w) == 0u) bg += 8;
+          else todo |= 1u << it;
+        }
+      }
+    }
+    // dense masks: a round in which at least MEAS_DIRECT lanes of the wave hold a labelled vector is visited in
+    // place (the lanes are busy anyway, and the queue would only add its traffic)
+#pragma unroll 1
+    for (int it = 0; it < MEAS_ITERS; ++it) {
+      const bool mine = (todo >> it) & 1u;
+      if (__builtin_popcountll(__ballot(mine)) >= MEAS_DIRECT) {   // wave-uniform
+        if (mine) visit(chunk0 + (it * MEAS_THREADS + tid) * VEC);
+        todo &= ~(1u << it);
+      }
+    }
+    if (todo) {
+      unsigned k = atomicAdd(&tb.qn, (unsigned)__builtin_popcount(todo));
+      while (todo) {
+        tb.queue[k++] = (unsigned short)(__builtin_ctz(todo) * MEAS_THREADS + tid);
+        todo &= todo - 1u;
+      }
+    }
+    __syncthreads();
+    const unsigned nq = tb.qn;
+    for (unsigned i = tid; i < nq; i += MEAS_THREADS) visit(chunk0 + (unsigned)tb.queue[i] * VEC);
+  } else {
+    for (int it = 0; it < MEAS_ITERS; ++it) {
+      const unsigned p = chunk0 + (it * MEAS_THREADS + tid) * VEC;
+      if (p >= zyx) break;
+      visit(p);
+    }
   }
 
   if (COORDS) {  // background count: wave shuffle reduction, one LDS add per wave

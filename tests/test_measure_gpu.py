@@ -147,3 +147,25 @@ def test_label_range_found_by_the_measuring_pass(dev, provisional, monkeypatch):
     assert acc.shape == (3, 41, 6)
     assert torch.equal(acc, ops.measure_accumulate(d, dl, 41))
     _check(img, lab, dev)
+
+
+@pytest.mark.parametrize("yx", [(256, 512), (96, 1004)])
+def test_dense_and_sparse_rounds_in_one_workgroup(dev, yx):
+    """The measuring pass visits a wave's round in place when at least half its lanes hold a labelled vector and
+    queues the labelled vectors of the other rounds in LDS: a frame whose upper part is densely labelled (every
+    8-pixel vector carries labels, two labels meeting inside vectors), whose lower part holds a few discs and a
+    sprinkle of single labelled pixels, takes both routes inside the same workgroups (16384-pixel chunks).
+    X = 1004: vectors straddle rows."""
+    y, x = yx
+    rng = np.random.default_rng(11)
+    t, c = 2, 3
+    img = rng.integers(0, 65536, size=(t, c, 1, y, x)).astype(np.uint16)
+    lab = np.zeros((t, 1, y, x), np.uint16)
+    for f in range(t):
+        cols = (np.arange(x) // 5 + 1 + 7 * f).astype(np.uint16)       # runs of 5: label borders inside vectors
+        lab[f, 0, : y // 3] = cols[None, :]
+        lab[f, 0, y // 3 :] = synth.make_labels(y - y // 3, x, 9, seed=20 + f) * 300
+        iy = rng.integers(y // 3, y, size=40)
+        ix = rng.integers(0, x, size=40)
+        lab[f, 0, iy, ix] = rng.integers(1, 65536, size=40)             # lone pixels, labels up to 65535
+    _check(img, lab, dev)
