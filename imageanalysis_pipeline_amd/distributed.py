@@ -17,6 +17,16 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
+# Rehearsal switch: with it set, a process group of ONE rank still runs every collective of this module instead of
+# taking the single-process shortcuts -- the only way to execute the RCCL branch (device tensors through
+# all_gather / all_reduce / broadcast) on a box with one GPU (tests/test_distributed_gpu.py).
+FORCE_COLLECTIVES = False
+
+
+def _exchanging(group=None) -> bool:
+    """True when this module's collectives have somebody to talk to (or are being rehearsed)."""
+    return dist.is_initialized() and (dist.get_world_size(group) > 1 or FORCE_COLLECTIVES)
+
 
 def shard_fovs(n_fov: int, rank: int, world: int) -> range:
     """Contiguous block distribution; the first (n_fov % world) ranks hold one extra FOV."""
@@ -42,7 +52,7 @@ def pack_rows(tables, fov: int) -> torch.Tensor:
 def gather_rows(rows: torch.Tensor, group=None) -> torch.Tensor:
     """Variable-length all_gather: every rank receives the concatenation (in rank order) of all
     ranks' row matrices.  Two collectives: row counts (int64), then the padded payload."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not _exchanging(group):
         return rows
     world = dist.get_world_size(group)
     if dist.get_backend(group) == "gloo":   # gloo gathers host tensors (tests, rehearsals); RCCL takes device ones
@@ -109,7 +119,7 @@ def process_plate(load_fov, n_fov: int, threshold: float, reg_ref: str = "mean",
     # ranks without FOVs still take part in the collective with an empty matrix of the right width
     width = torch.tensor([rows.shape[1] if rows is not None else 0], dtype=torch.int64,
                          device=parts[0].device if parts else ("cuda" if torch.cuda.is_available() else "cpu"))
-    if dist.is_initialized() and world > 1:
+    if _exchanging(group):
         if dist.get_backend(group) == "gloo":
             width = width.cpu()
         dist.all_reduce(width, op=dist.ReduceOp.MAX, group=group)
@@ -131,7 +141,7 @@ def reference_plane(planes: torch.Tensor, t0: int, n_frames: int, reg_ref: str, 
              the very values iap_im_reg_u16 feeds its reference spectrum (sum as f32, scaled on load)."""
     if reg_ref not in ("first", "mean"):
         raise ValueError(f"time blocks cannot shard reg_ref={reg_ref!r} ('previous' is serial in time)")
-    multi = dist.is_initialized() and dist.get_world_size(group) > 1
+    multi = _exchanging(group)
     host = multi and dist.get_backend(group) == "gloo"      # gloo moves host tensors (tests, rehearsals)
     dev = planes.device
     if reg_ref == "first":

@@ -159,3 +159,60 @@ def test_two_ranks_equal_one_process(dev):
         assert np.array_equal(tb_rows, tb_ref)               # time blocks: the rows of a single-process run
         fr = D.shard_frames(T, rank, world)
         assert np.array_equal(tb_sh, sh[fr.start:fr.stop])
+
+
+def _rccl_worker(port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        try:
+            D.FORCE_COLLECTIVES = True      # one rank, but every collective runs: device tensors through RCCL
+            thr = O.smo_threshold((Y, X))
+            plate = D.process_plate(lambda i: _fov(i, dev)[2:], 3, thr, reg_ref="mean")
+            _, _, st, lab = _fov(0, dev)
+            out = [plate.cpu().numpy()]
+            for reg_ref in ("mean", "first"):
+                rows, sh = D.process_fov_timeblocks(lambda t0, t1: (st[t0:t1].contiguous(), lab[t0:t1].contiguous()),
+                                                    T, thr, reg_ref=reg_ref, fov=0)
+                out += [rows.cpu().numpy(), sh.cpu().numpy()]
+            tt = torch.tensor([1.5], dtype=torch.float64, device=dev)     # bench.py's max-over-ranks of the step time
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dist.barrier()
+            out.append(float(tt.item()))
+            q.put(("ok", out))
+        finally:
+            dist.destroy_process_group()
+    except BaseException as e:  # noqa: BLE001
+        q.put(("failed", f"{type(e).__name__}: {e}"))
+        raise
+
+
+def test_rccl_branch_with_one_rank(dev):
+    """The RCCL ("nccl") branch of the gathers and of the reference-plane exchange, executed for real: a one-rank
+    process group with the single-process shortcuts switched off (distributed.FORCE_COLLECTIVES).  Counts, padded
+    payload, width reduction, the int64 plane-sum all_reduce, the byte broadcast of frame 0 and bench.py's float64
+    MAX all go through RCCL on device tensors; the results equal the plain single-process run."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    try:
+        status, out = q.get(timeout=170)
+        assert status == "ok", out
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    finally:
+        if p.is_alive():
+            p.terminate()
+            p.join(timeout=10)
+    thr = O.smo_threshold((Y, X))
+    assert np.array_equal(out[0], _sequential_rows(dev, thr, "mean", range(3)).cpu().numpy())
+    _, _, st, lab = _fov(0, dev)
+    bg, _, _ = ops.bg_smo(st, thr)
+    for k, reg_ref in enumerate(("mean", "first")):
+        reg, sh = ops.im_reg(bg, 0, reg_ref)
+        ref = D.pack_rows(ops.measure_finalize(ops.measure_accumulate(reg, lab)), 0).cpu().numpy()
+        assert np.array_equal(out[1 + 2 * k], ref) and np.array_equal(out[2 + 2 * k], sh.cpu().numpy())
+    assert out[5] == 1.5
