@@ -468,7 +468,7 @@ def main():
     ap.add_argument("--tblock", type=int, default=-1, help="frames registered + measured at a time (0: whole stack)")
     ap.add_argument("--reg-ref", default="mean", choices=["first", "mean", "previous"],
                     help="reference frame of the registration; 'mean' is the reference's default (core.py:77) and what its notebook passes")
-    ap.add_argument("--batch", type=int, default=0, help="frames per registration launch group (0: the library wrapper's choice, 64 at 2048^2)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per registration launch group (0: the library wrapper's choice, 128 at 2048^2)")
     ap.add_argument("--two-pass", action="store_true", help="write the background-subtracted stack, then register it")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")

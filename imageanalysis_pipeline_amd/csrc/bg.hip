@@ -165,7 +165,9 @@ __global__ __launch_bounds__(SMO_WAVES * 64, 3) void smo_march_kernel(
   __shared__ unsigned lds_fine[SMO_WAVES][SMO_WIN];
   __shared__ unsigned lds_coarse[SMO_WAVES][HIST_COARSE];
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  // (read back through a scalar register: the compiler cannot know that threadIdx.x >> 6 is the same for a whole
+  // wave, and would otherwise carry the strip, the band, the row counter and every row address in vector registers)
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int Y = g.Y, X = g.X;
   const long long task_all = (long long)blockIdx.x * SMO_WAVES + wave;
   const long long plane = task_all / g.tasks_per_plane;
@@ -366,6 +368,31 @@ __global__ __launch_bounds__(SMO_WAVES * 64, 3) void smo_march_kernel(
 
   int oy = y0 + 1;
   // fast groups need rows oy+3 .. oy+9 strictly inside the plane and the prefetch row oy+13 <= Y-1
+  // three ring rounds per trip: the three row registers (A, B, Cn) rotate with period 3, the ring with period 7, and
+  // only after 21 steps is every value back in the register it started in (no copies at the back edge)
+  while (oy + 21 <= yend && oy + 27 < Y && oy + 3 > 0) {
+    SMO_STEP(0, SMO_FILL_FAST);
+    SMO_STEP(1, SMO_FILL_FAST);
+    SMO_STEP(2, SMO_FILL_FAST);
+    SMO_STEP(3, SMO_FILL_FAST);
+    SMO_STEP(4, SMO_FILL_FAST);
+    SMO_STEP(5, SMO_FILL_FAST);
+    SMO_STEP(6, SMO_FILL_FAST);
+    SMO_STEP(0, SMO_FILL_FAST);
+    SMO_STEP(1, SMO_FILL_FAST);
+    SMO_STEP(2, SMO_FILL_FAST);
+    SMO_STEP(3, SMO_FILL_FAST);
+    SMO_STEP(4, SMO_FILL_FAST);
+    SMO_STEP(5, SMO_FILL_FAST);
+    SMO_STEP(6, SMO_FILL_FAST);
+    SMO_STEP(0, SMO_FILL_FAST);
+    SMO_STEP(1, SMO_FILL_FAST);
+    SMO_STEP(2, SMO_FILL_FAST);
+    SMO_STEP(3, SMO_FILL_FAST);
+    SMO_STEP(4, SMO_FILL_FAST);
+    SMO_STEP(5, SMO_FILL_FAST);
+    SMO_STEP(6, SMO_FILL_FAST);
+  }
   while (oy + 7 <= yend && oy + 13 < Y && oy + 3 > 0) {
     SMO_STEP(0, SMO_FILL_FAST);
     SMO_STEP(1, SMO_FILL_FAST);

@@ -280,10 +280,12 @@ def gauss_blur(planes: torch.Tensor, ksize=(15, 15), sigma: float = 5.0) -> torc
 
 # ----------------------------------------------------------------------------- registration
 
-DEFAULT_REG_BATCH = 64   # frames per launch group at 2048^2: C2 estimate 17.5 / 13.7 / 13.4 / 12.8 / 12.65 ms at 4 / 8 / 16 / 32 / 64
-REG_GROUP_BYTES = 2 << 30   # ... and, with ``batch=None``, as many frames as this much workspace holds, never fewer than 64
-                            # (25.5 MB per frame at 2048^2: 64-frame groups there -- one 500-frame group was measured
-                            # slower, the column pass then finds none of the row pass's output in the caches: 7.2
+DEFAULT_REG_BATCH = 64   # fewest frames per launch group: C2 estimate 17.5 / 13.7 / 13.4 / 12.8 / 12.65 ms at 4 / 8 / 16 / 32 / 64 (round 2)
+REG_GROUP_BYTES = 4 << 30   # ... and, with ``batch=None``, as many frames as this much workspace holds, never fewer than 64
+                            # (25.5 MB per frame at 2048^2: 128-frame groups there, C2 estimate 11.18 -> 10.99 ms against
+                            # 64-frame groups in three alternating runs of round 3; groups of 7 .. 47 frames, sized
+                            # for the Infinity Cache, were slower (16.2 .. 11.0 ms) and so was one 500-frame group
+                            # in round 2, whose column pass finds none of the row pass's output in the caches: 7.2
                             # against 5.9 ms; small planes: one group, fewer launches)
 
 

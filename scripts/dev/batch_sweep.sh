@@ -1,6 +1,6 @@
 #!/bin/bash
 # estimate stage against the registration launch group size (GPU box)
-for b in 64 7 15 23 31 47; do
+for b in ${BATCHES:-64 72 84 100 125 167}; do
   timeout -k 10 120 python -u bench.py --batch $b --no-traffic --no-cpu-baseline --no-verify 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])

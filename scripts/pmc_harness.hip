@@ -159,7 +159,7 @@ int main(int argc, char** argv) {
     for (int k = 0; k < reps; ++k) IAP(iap_bg_smo_u16(in, nullptr, n, Y, X, 1.0f, 7, 0.0455f, med2, nullptr, ws, wsb, nullptr));
     CK(hipEventRecord(e1));
   } else if (!strcmp(stage, "estimate")) {
-    const int bmax = getenv("IAP_HARNESS_BATCH") ? atoi(getenv("IAP_HARNESS_BATCH")) : 64;   // frames per launch group (workspace size)
+    const int bmax = getenv("IAP_HARNESS_BATCH") ? atoi(getenv("IAP_HARNESS_BATCH")) : 128;   // frames per launch group (workspace size; ops.py picks 128 at 2048^2)
     const int batch = (int)(n < bmax ? n : bmax);
     const size_t wsb = iap_reg_ws_bytes(Y, X, 1, batch);
     void* ws;
