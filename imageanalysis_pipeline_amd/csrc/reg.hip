@@ -288,6 +288,33 @@ __device__ __forceinline__ void fft_fwd_open_rec(cf* s, int j, const cf* __restr
     fft_fwd_open_rec<N, E, Ns * R>(s, j, tw, x);
   }
 }
+// Transform whose LAST pass stays in registers, either direction, for a consumer that only looks at the values:
+// x[m] is element pos[m] of the result (the inverse row pass takes the arg-max straight from them -- the last
+// pass's stores, the barrier behind them and the read-back are a fifth of that kernel's LDS traffic).
+template <int N, int E, int SIGN, int Ns>
+__device__ __forceinline__ void fft_open_rec(cf* s, int j, const cf* __restrict__ tw, cf (&x)[E], int (&pos)[E]) {
+  constexpr int R = pass_radix<N, E, Ns>();
+  if constexpr (Ns * R == N) {
+    constexpr int NB = E / R, NT = N / E;
+    cf v[NB][R];
+    fft_pass_read<N, E, R, SIGN, Ns>(s, j, tw, v);
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        x[b * R + r] = v[b][r];
+        pos[b * R + r] = j + b * NT + r * Ns;   // butterfly jj = j + b NT < Ns: its outputs are jj + r Ns
+      }
+  } else {
+    fft_pass<N, E, R, SIGN, Ns>(s, j, tw);
+    fft_open_rec<N, E, SIGN, Ns * R>(s, j, tw, x, pos);
+  }
+}
+template <int N, int SIGN, int E = 8>
+__device__ __forceinline__ void fft_lds_open(cf* s, int j, const cf* __restrict__ tw, cf (&x)[E], int (&pos)[E]) {
+  static_assert(pass_radix<N, E, 1>() < N, "at least two passes");
+  fft_open_rec<N, E, SIGN, 1>(s, j, tw, x, pos);
+}
 template <int N, int E>
 __device__ __forceinline__ void fft_fwd_open(cf* s, int j, const cf* __restrict__ tw, cf (&x)[E]) {
   static_assert(pass_radix<N, E, 1>() < N, "at least two passes");
@@ -894,15 +921,15 @@ __global__ __launch_bounds__(FftGeom<N>::RPQ* FftGeom<N>::NT) void rows_c2r_argm
     if (k0 == 0) put(N / 2, __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Qf + q_at(yl, N / 2, Wp))));
   }
   __syncthreads();
-  fft_lds<N, +1>(s, j, tw);
+  cf z[8];
+  int zn[8];
+  fft_lds_open<N, +1>(s, j, tw, z, zn);   // the surface rows never go back to LDS
   float bv = -INFINITY;
   int bi = 0x7fffffff;
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
-    int n = j + m * Gm::NT;
-    cf z = s[padi<8>(n)];
-    amax_take(bv, bi, z.x, ra * N + n);
-    amax_take(bv, bi, z.y, rb * N + n);
+    amax_take(bv, bi, z[m].x, ra * N + zn[m]);
+    amax_take(bv, bi, z[m].y, rb * N + zn[m]);
   }
   block_argmax(bv, bi, shv, shi);
   if (threadIdx.x == 0) {
