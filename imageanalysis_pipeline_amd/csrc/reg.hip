@@ -289,7 +289,7 @@ __device__ __forceinline__ void fft_fwd_open_rec(cf* s, int j, const cf* __restr
   }
 }
 // Transform whose LAST pass stays in registers, either direction, for a consumer that only looks at the values:
-// x[m] is element pos[m] of the result (the inverse row pass takes the arg-max straight from them -- the last
+// x[m] is element pos[m] of the result, pos[] increasing (the inverse row pass takes the arg-max straight from them -- the last
 // pass's stores, the barrier behind them and the read-back are a fifth of that kernel's LDS traffic).
 template <int N, int E, int SIGN, int Ns>
 __device__ __forceinline__ void fft_open_rec(cf* s, int j, const cf* __restrict__ tw, cf (&x)[E], int (&pos)[E]) {
@@ -302,8 +302,8 @@ __device__ __forceinline__ void fft_open_rec(cf* s, int j, const cf* __restrict_
     for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        x[b * R + r] = v[b][r];
-        pos[b * R + r] = j + b * NT + r * Ns;   // butterfly jj = j + b NT < Ns: its outputs are jj + r Ns
+        x[r * NB + b] = v[b][r];               // in increasing order of position (NB NT = Ns)
+        pos[r * NB + b] = j + b * NT + r * Ns;   // butterfly jj = j + b NT < Ns: its outputs are jj + r Ns
       }
   } else {
     fft_pass<N, E, R, SIGN, Ns>(s, j, tw);
@@ -926,11 +926,20 @@ __global__ __launch_bounds__(FftGeom<N>::RPQ* FftGeom<N>::NT) void rows_c2r_argm
   fft_lds_open<N, +1>(s, j, tw, z, zn);   // the surface rows never go back to LDS
   float bv = -INFINITY;
   int bi = 0x7fffffff;
+  // the thread's candidates in increasing order of index (row ra before rb, positions increasing): a strictly
+  // larger value takes over, so ties keep the smaller index as amax_take would, at half its instructions
 #pragma unroll
-  for (int m = 0; m < 8; ++m) {
-    amax_take(bv, bi, z[m].x, ra * N + zn[m]);
-    amax_take(bv, bi, z[m].y, rb * N + zn[m]);
-  }
+  for (int m = 0; m < 8; ++m)
+    if (z[m].x > bv) {
+      bv = z[m].x;
+      bi = ra * N + zn[m];
+    }
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+    if (z[m].y > bv) {
+      bv = z[m].y;
+      bi = rb * N + zn[m];
+    }
   block_argmax(bv, bi, shv, shi);
   if (threadIdx.x == 0) {
     pval[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = bv;
