@@ -182,6 +182,10 @@ __global__ __launch_bounds__(SMO_WAVES * 64, 3) void smo_march_kernel(
   const int own_hi = right_strip ? X : own_lo + SMO_COLS;
   const int xl = x0 + 4 * lane;                 // first column of this lane
   const bool col_ok = xl >= 0 && xl + 3 < X;    // X % 4 == 0: a lane is entirely in or out
+  // A lane outside the image (lane 0 of the leftmost strip, lane 63 of the rightmost) loads the image's edge columns
+  // instead of nothing: its values are never used -- its neighbour mirrors its own columns (mir_l / mir_r, edge_l /
+  // edge_r) and it owns no output -- and an unconditional load needs no zeroed destination and no branch per row.
+  const int xl_ld = min(max(xl, 0), X - 4);
   const int y0 = bandi * g.band;
   const int yend = min(Y, y0 + g.band);
   const bool top = y0 == 0;
@@ -219,11 +223,11 @@ __global__ __launch_bounds__(SMO_WAVES * 64, 3) void smo_march_kernel(
   ln.fx_l = ln.edge_l ? 2.0f : 1.0f;
   ln.fx_r = ln.edge_r ? 2.0f : 1.0f;
   // rows v-1, v, v+1 of the row being computed; rows v+2 and v+3 are in flight, unconverted
-  f4 A = load_row4<T>(p + (size_t)max(vfirst - 1, 0) * X, xl, col_ok);
-  f4 B = load_row4<T>(p + (size_t)vfirst * X, xl, col_ok);
-  f4 Cn = load_row4<T>(p + (size_t)min(vfirst + 1, Y - 1) * X, xl, col_ok);
-  Raw4<T> Dn = load_raw4<T>(p + (size_t)min(vfirst + 2, Y - 1) * X, xl, col_ok);
-  Raw4<T> En = load_raw4<T>(p + (size_t)min(vfirst + 3, Y - 1) * X, xl, col_ok);
+  f4 A = load_row4<T>(p + (size_t)max(vfirst - 1, 0) * X, xl_ld, true);
+  f4 B = load_row4<T>(p + (size_t)vfirst * X, xl_ld, true);
+  f4 Cn = load_row4<T>(p + (size_t)min(vfirst + 1, Y - 1) * X, xl_ld, true);
+  Raw4<T> Dn = load_raw4<T>(p + (size_t)min(vfirst + 2, Y - 1) * X, xl_ld, true);
+  Raw4<T> En = load_raw4<T>(p + (size_t)min(vfirst + 3, Y - 1) * X, xl_ld, true);
   // u16 source == histogram source: the unconverted rows are kept in a 7-slot ring (same slot
   // numbering as ry/rx) so that emit() never re-reads the image
   constexpr bool RAWRING = (MODE == SMO_MODE_HIST) && sizeof(T) == 2;
@@ -231,8 +235,8 @@ __global__ __launch_bounds__(SMO_WAVES * 64, 3) void smo_march_kernel(
 #pragma unroll
   for (int q = 0; q < 7; ++q) rawr[q] = make_uint2(0u, 0u);
   if (RAWRING && top) {  // rows 0 and 1 live in slots 3 and 4
-    rawr[3] = as_u2(load_raw4<T>(p, xl, col_ok));
-    rawr[4] = as_u2(load_raw4<T>(p + (size_t)X, xl, col_ok));
+    rawr[3] = as_u2(load_raw4<T>(p, xl_ld, true));
+    rawr[4] = as_u2(load_raw4<T>(p + (size_t)X, xl_ld, true));
   }
 
   // Put virtual row v into ring slot PH (PH is a compile-time constant after unrolling).
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(SMO_WAVES * 64, 3) void smo_march_kernel(
       Cn = to_f4(Dn);                                                                                \
       if (RAWRING) rawr[((PH) + 2) % 7] = as_u2(Dn);                      \
       Dn = En;                                                                                       \
-      En = load_raw4<T>(p + (size_t)min((VROW) + 4, Y - 1) * X, xl, col_ok);                            \
+      En = load_raw4<T>(p + (size_t)min((VROW) + 4, Y - 1) * X, xl_ld, true);                            \
       ry[PH][0] = hy_.lo; ry[PH][1] = hy_.hi;                                                        \
       rx[PH][0] = hx_.lo; rx[PH][1] = hx_.hi;                                                        \
     } else {                                                                                         \
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(SMO_WAVES * 64, 3) void smo_march_kernel(
     Cn = to_f4(Dn);                                                                                  \
     if (RAWRING) rawr[((PH) + 2) % 7] = as_u2(Dn);                        \
     Dn = En;                                                                                         \
-    En = load_raw4<T>(p + (size_t)((VROW) + 4) * X, xl, col_ok);                                      \
+    En = load_raw4<T>(p + (size_t)((VROW) + 4) * X, xl_ld, true);                                      \
     ry[PH][0] = hy_.lo; ry[PH][1] = hy_.hi;                                                          \
     rx[PH][0] = hx_.lo; rx[PH][1] = hx_.hi;                                                          \
   } while (0)
