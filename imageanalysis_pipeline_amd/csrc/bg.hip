@@ -292,6 +292,7 @@ __global__ __launch_bounds__(SMO_WAVES * 64, 3) void smo_march_kernel(
   SMO_RESUM();
 
   const bool lane_own = lane >= 1 && lane <= 62 && xl >= own_lo && xl < own_hi;
+  const float thr2_lane = lane_own ? thr2 : -1.0f;   // no squared magnitude is below -1: halo lanes never count
   auto emit = [&](int oy, const uint2& rawrow) {
     if (MODE == SMO_MODE_IMAGE) {
       if (lane_own) {
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(SMO_WAVES * 64, 3) void smo_march_kernel(
       bool any = false;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        bgp[i] = lane_own && (mag2[i] < thr2);
+        bgp[i] = mag2[i] < thr2_lane;
         any |= bgp[i];
       }
       if (any) {  // ~5 % of the background pixels pass: most lanes skip the whole block
