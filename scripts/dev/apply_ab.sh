@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 for v in "$@"; do
   if [ "$v" = tree ]; then unset LD_LIBRARY_PATH; else export LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/build/$v; fi
   echo "== $v"
-  for m in "" x y yx; do
+  for m in ${MODES:-"" x y yx}; do
     echo -n "whole[$m] "; IAP_HARNESS_SHIFT=$m timeout -k 10 120 ./scripts/pmc_harness apply 500 4 || exit 1
   done
 done
