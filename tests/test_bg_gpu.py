@@ -238,3 +238,26 @@ def test_smo_sigma_prefilter_paths(dev, sigma):
         exp = O.smo_image(img[0].astype(np.float64), sigma, 7)
         # as test_smo_image_and_threshold_with_sigma: fp32 smoothed plane, differences of neighbours a count apart
         assert np.quantile(np.abs(got - exp), 0.999) <= 3e-4, (sigma, y, x, np.abs(got - exp).max())
+
+
+def test_bg_levels_over_several_batches(dev):
+    """More planes than one batch of histograms holds (256): the histograms are zeroed once per call and handed back
+    clean by the median kernel, so the levels of later batches must equal those of the same planes taken alone --
+    planes of very different backgrounds follow each other, a plane of noise over the full u16 range (background
+    outside every LDS window) sits at the start of each batch."""
+    from imageanalysis_pipeline_amd import ops
+    rng = np.random.default_rng(21)
+    n, y, x = 700, 16, 256
+    img = (rng.poisson(30, size=(n, y, x)) + rng.integers(100, 60000, size=(n, 1, 1))).clip(0, 65535).astype(np.uint16)
+    img[::256] = rng.integers(0, 65536, size=(3, y, x)).astype(np.uint16)
+    d = ops.to_device_u16(img, dev)
+    med_all, nbg_all = ops.bg_smo_levels(d, 0.06)
+    for lo, hi in ((0, 3), (255, 259), (511, 515), (690, 700)):
+        med, nbg = ops.bg_smo_levels(d[lo:hi].contiguous(), 0.06)
+        assert torch.equal(med, med_all[lo:hi]) and torch.equal(nbg, nbg_all[lo:hi])
+    for i in (0, 256, 300, 512, 699):
+        _, em2, en, _ = O.bg_smo(img[i], 0.06)
+        assert int(med_all[i]) == em2
+    # a second call on the same workspace (left clean by the first) gives the same levels
+    med2, _ = ops.bg_smo_levels(d, 0.06)
+    assert torch.equal(med2, med_all)
