@@ -452,9 +452,9 @@ template <> struct Sp<true> {
 };
 
 // two real rows per complex transform: Fa[k] = (Z[k] + conj Z[N-k]) / 2, Fb[k] = (Z[k] - conj Z[N-k]) / 2i
-template <int N>
+template <int N, int E = 8>
 __device__ __forceinline__ void split_rows(const cf* sp, int k, cf& fa, cf& fb) {
-  const cf zk = sp[padi<8>(k)], zn = sp[padi<8>((N - k) & (N - 1))];
+  const cf zk = sp[padi<E>(k)], zn = sp[padi<E>((N - k) & (N - 1))];
   fa = mkc(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
   fb = mkc(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
 }
@@ -501,51 +501,69 @@ __global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_r2c_kernel
 // step's results wait in registers (16 bytes per thread and round) while the second step's rows, requested before
 // the first transform started, go through the same LDS, and both leave together as 32 contiguous bytes per column --
 // whole lines from one wave, with the workgroups as small as the transforms allow (four per CU at 2048 points).
+// Rows of 1024 points and more are transformed with 16 points per thread, as in the inverse row pass (three LDS
+// passes instead of four, half the threads, padded index): 533-542 against 594-601 us per 128 frames of 2048^2.
+#ifndef R2C_E
+#define R2C_E 16
+#endif
 template <int N>
 struct R16Geom {
   using Gm = FftGeom<N>;
-  static constexpr int PS = Gm::G >= 4 ? Gm::G : 2;      // row pairs per step
-  static constexpr int STEPS = Gm::G >= 4 ? 1 : 2;
-  static constexpr int NTH = PS * Gm::NT;
+  static constexpr int E = N >= 1024 ? R2C_E : 8;        // points per thread of the transform
+  static constexpr int NT = N / E;                       // threads per transform
+  static constexpr int PADN = E >= 16 ? N + N / 16 : Gm::PADN;   // LDS points per transform (padi<E>)
+  static constexpr int G = (256 / NT) > 1 ? (256 / NT) : 1;
+  static constexpr int PS = G >= 4 ? G : 2;              // row pairs per step
+  static constexpr int STEPS = G >= 4 ? 1 : 2;
+  static constexpr int NTH = PS * NT;
   static constexpr int ROWS = 2 * PS * STEPS;            // rows per workgroup: a multiple of 8
   static constexpr int NQ = PS / 2;                      // row quads per step
   static constexpr int LG = NTH / NQ < 32 ? NTH / NQ : 32;
-  static constexpr int KSTEP = NTH / NQ;                 // = 2 NT = N / 4: two rounds cover the bins below Nyquist
-  static_assert(ROWS % 8 == 0 && NTH % (LG * NQ) == 0 && KSTEP * 2 == N / 2, "row blocks, lane groups, rounds");
+  static constexpr int KSTEP = NTH / NQ;                 // bins a round of stores covers
+  static constexpr int NR = (N / 2) / KSTEP;             // rounds that cover the bins below Nyquist (2 at 8 points per thread)
+  static constexpr int WPS = E >= 16 ? 4 : 8;            // waves per SIMD the kernel is compiled for
+  static_assert(ROWS % 8 == 0 && NTH % (LG * NQ) == 0 && KSTEP * NR == N / 2, "row blocks, lane groups, rounds");
 };
 template <int N, bool vec, bool F32>
-__global__ __launch_bounds__(R16Geom<N>::NTH, 8) void rows_r2c16_kernel(
+__global__ __launch_bounds__(R16Geom<N>::NTH, R16Geom<N>::WPS) void rows_r2c16_kernel(
     const uint16_t* __restrict__ src, long long plane_stride, int srcX, int oy, int ox, typename Sp<F32>::E* __restrict__ F,
     long long F_stride, int Wp, const cf* __restrict__ tw, const int* __restrict__ sub2, long long sub_stride) {
-  using Gm = FftGeom<N>;
   using Rg = R16Geom<N>;
+  constexpr int E = Rg::E, NV = E / 8;
   extern __shared__ cf lds_c[];
   const int t = threadIdx.x;
-  const int g = t / Gm::NT;
-  int j = t % Gm::NT;
-  cf* s = lds_c + g * Gm::PADN;
+  const int g = t / Rg::NT;
+  int j = t % Rg::NT;
+  cf* s = lds_c + g * Rg::PADN;
   const int r0 = blockIdx.x * Rg::ROWS;
   const int lv = plane_level(sub2, (long long)blockIdx.y * sub_stride);
   const float in_scale = fs16<N>();
   const uint16_t* p = src + (size_t)blockIdx.y * plane_stride + (size_t)oy * srcX + ox;
   auto row_of = [&](int step) { return r0 + step * 2 * Rg::PS + 2 * g; };
-  // 16-byte aligned rows: one 8-pixel vector per row and thread, fetched a step ahead
-  auto fetch = [&](int step, u16x8& qa, u16x8& qb) {
+  // 16-byte aligned rows: E / 8 8-pixel vectors per row and thread (vector j + v NT: a wave reads whole lines),
+  // fetched a step ahead
+  auto fetch = [&](int step, u16x8 (&qa)[NV], u16x8 (&qb)[NV]) {
     const uint16_t* pa = p + (size_t)row_of(step) * srcX + 8 * j;
-    qa = load8(pa);
-    qb = load8(pa + srcX);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      qa[v] = load8(pa + 8 * v * Rg::NT);
+      qb[v] = load8(pa + 8 * v * Rg::NT + srcX);
+    }
   };
-  auto stage = [&](int step, const u16x8& qa, const u16x8& qb) {
+  auto stage = [&](int step, const u16x8 (&qa)[NV], const u16x8 (&qb)[NV]) {
     if (vec) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
-        s[padi<8>(8 * j + k)] = mkc((float)max((int)qa.v[k] - lv, 0) * in_scale, (float)max((int)qb.v[k] - lv, 0) * in_scale);
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          s[padi<E>(8 * (j + v * Rg::NT) + k)] =
+              mkc((float)max((int)qa[v].v[k] - lv, 0) * in_scale, (float)max((int)qb[v].v[k] - lv, 0) * in_scale);
     } else {
       const uint16_t* pa = p + (size_t)row_of(step) * srcX;
 #pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const int n = j + m * Gm::NT;
-        s[padi<8>(n)] = mkc((float)max((int)pa[n] - lv, 0) * in_scale, (float)max((int)pa[srcX + n] - lv, 0) * in_scale);
+      for (int m = 0; m < E; ++m) {
+        const int n = j + m * Rg::NT;
+        s[padi<E>(n)] = mkc((float)max((int)pa[n] - lv, 0) * in_scale, (float)max((int)pa[srcX + n] - lv, 0) * in_scale);
       }
     }
   };
@@ -553,44 +571,47 @@ __global__ __launch_bounds__(R16Geom<N>::NTH, 8) void rows_r2c16_kernel(
   // (conflict-free LDS reads)
   const int q = (t / Rg::LG) % Rg::NQ;
   const int k0 = (t % Rg::LG) + Rg::LG * (t / (Rg::LG * Rg::NQ));   // < KSTEP
-  const cf* sa = lds_c + (2 * q) * Gm::PADN;
-  const cf* sb = sa + Gm::PADN;
+  const cf* sa = lds_c + (2 * q) * Rg::PADN;
+  const cf* sb = sa + Rg::PADN;
   auto quad = [&](int k) {
     cf f0, f1, f2, f3;
-    split_rows<N>(sa, k, f0, f1);
-    split_rows<N>(sb, k, f2, f3);
+    split_rows<N, E>(sa, k, f0, f1);
+    split_rows<N, E>(sb, k, f2, f3);
     return Sp<F32>::pack(f0, f1, f2, f3);
   };
   typedef typename Sp<F32>::E FE;
   typedef typename Sp<F32>::P4 P4;
   FE* Fo = F + (size_t)blockIdx.y * F_stride;
-  u16x8 qa, qb;
+  u16x8 qa[NV], qb[NV];
   if (vec) fetch(0, qa, qb);
   stage(0, qa, qb);
   __syncthreads();
   if (Rg::STEPS == 2 && vec) fetch(1, qa, qb);
-  fft_lds<N, -1>(s, j, tw);
-  fft_publish<Gm::NT>();   // the quads are read across the transforms' own thread groups
+  fft_lds<N, -1, E>(s, j, tw);
+  fft_publish<Rg::NT>();   // the quads are read across the transforms' own thread groups
   if constexpr (Rg::STEPS == 1) {
     const int y0 = r0 + 4 * q;
-    Sp<F32>::store(Fo + f_at(y0, k0, Wp), quad(k0));
-    Sp<F32>::store(Fo + f_at(y0, k0 + Rg::KSTEP, Wp), quad(k0 + Rg::KSTEP));
+#pragma unroll
+    for (int r = 0; r < Rg::NR; ++r) Sp<F32>::store(Fo + f_at(y0, k0 + r * Rg::KSTEP, Wp), quad(k0 + r * Rg::KSTEP));
     if (k0 == 0) Sp<F32>::store(Fo + f_at(y0, N / 2, Wp), quad(N / 2));
   } else {
     static_assert(Rg::STEPS == 1 || Rg::NQ == 1, "two steps: one quad per step");
-    const P4 a0 = quad(k0), a1 = quad(k0 + Rg::KSTEP);
+    P4 a[Rg::NR];
+#pragma unroll
+    for (int r = 0; r < Rg::NR; ++r) a[r] = quad(k0 + r * Rg::KSTEP);
     FE* o = Fo + f_at(r0, k0, Wp);          // rows r0 .. r0 + 3 of column k0, rows r0 + 4 .. + 7 behind them
     if (k0 == 0) Sp<F32>::store(o + (size_t)(N / 2) * 8, quad(N / 2));   // (the Nyquist column: half lines)
     __syncthreads();   // the first step's spectra are in registers
     stage(1, qa, qb);
     __syncthreads();
     asm volatile("" : "+v"(j));   // the second transform works out its LDS offsets anew instead of holding the first one's
-    fft_lds<N, -1>(s, j, tw);
-    fft_publish<Gm::NT>();
-    Sp<F32>::store(o, a0);
-    Sp<F32>::store(o + 4, quad(k0));
-    Sp<F32>::store(o + (size_t)Rg::KSTEP * 8, a1);
-    Sp<F32>::store(o + (size_t)Rg::KSTEP * 8 + 4, quad(k0 + Rg::KSTEP));
+    fft_lds<N, -1, E>(s, j, tw);
+    fft_publish<Rg::NT>();
+#pragma unroll
+    for (int r = 0; r < Rg::NR; ++r) {
+      Sp<F32>::store(o + (size_t)r * Rg::KSTEP * 8, a[r]);
+      Sp<F32>::store(o + (size_t)r * Rg::KSTEP * 8 + 4, quad(k0 + r * Rg::KSTEP));
+    }
     if (k0 == 0) Sp<F32>::store(o + (size_t)(N / 2) * 8 + 4, quad(N / 2));
   }
 }
@@ -1962,7 +1983,7 @@ static int launch_rows_r2c(const RegPlan& p, const void* src, int kind, long lon
       static_assert(FftGeom<N>::RPQ == (256 / (N / 8) > 2 ? 256 / (N / 8) : 2), "geom_rows_RPQ");
       using Rg = R16Geom<N>;
       if (kind != 0 || in_scale != 1.0f) return IAP_E_ARG;   // the moving planes are u16
-      const size_t lds = (size_t)Rg::PS * Gm::PADN * sizeof(cf);
+      const size_t lds = (size_t)Rg::PS * Rg::PADN * sizeof(cf);
       if (p.fb == 8) {
         if (vec) IAP_R2C16(true, true); else IAP_R2C16(false, true);
       } else {
