@@ -397,6 +397,9 @@ __device__ __forceinline__ float load_src(const void* __restrict__ p, int kind, 
   return reinterpret_cast<const float*>(p)[i];
 }
 
+#ifndef ROWS_E16_MIN
+#define ROWS_E16_MIN 1024   // shortest row that the row kernels transform with 16 points per thread (512: C1 estimate 0.213 against 0.206 ms)
+#endif
 // K1 ---------------------------------------------------------------------------------------
 // Row spectra are stored in one of two forms.  The moving planes' (always u16 data, so |F| <= Px * 65535) go
 // to HBM as packed half pairs, scaled by FS16<N> = 0.5 / Px: half the bytes of the path's largest scratch
@@ -509,7 +512,7 @@ __global__ __launch_bounds__(FftGeom<N>::G* FftGeom<N>::NT) void rows_r2c_kernel
 template <int N>
 struct R16Geom {
   using Gm = FftGeom<N>;
-  static constexpr int E = N >= 1024 ? R2C_E : 8;        // points per thread of the transform
+  static constexpr int E = N >= ROWS_E16_MIN ? R2C_E : 8;        // points per thread of the transform
   static constexpr int NT = N / E;                       // threads per transform
   static constexpr int PADN = E >= 16 ? N + N / 16 : Gm::PADN;   // LDS points per transform (padi<E>)
   static constexpr int G = (256 / NT) > 1 ? (256 / NT) : 1;
@@ -908,7 +911,7 @@ __device__ __forceinline__ void block_argmax(float& v, int& i, float* shv, int* 
 #endif
 template <int N>
 struct C2rGeom {
-  static constexpr int E = N >= 1024 ? C2R_E : 8;
+  static constexpr int E = N >= ROWS_E16_MIN ? C2R_E : 8;
   static constexpr int NT = N / E;                                            // threads per transform
   static constexpr int PADN = E >= 16 ? N + N / 16 : FftGeom<N>::PADN;        // LDS points per transform (padi<E>)
   static constexpr int RPQ = FftGeom<N>::RPQ;
